@@ -1,0 +1,111 @@
+/*
+ * litho_abbe.h -- C ABI of the MI355X (gfx950) Abbe aerial-image engine.
+ *
+ * Drop-in boundary for the hot path of quarterwave0/LithographySimulator.  The
+ * reference is pure Python over torch and has no FFI of its own; these entry points
+ * are what a binding for that path would call (ctypes stub: INTEGRATION.md), one per
+ * reference callable.  Each comment names the reference interface it replaces.
+ *
+ * Conventions (all functions):
+ *   - return 0 on success, a negative LITHO_E_* code otherwise; never throw, never abort;
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - complex64 arrays are interleaved (re, im) fp32, row-major, exactly torch's layout;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream)
+ *     and the call returns without waiting for it, except where a comment says
+ *     "reads back": those calls copy a few bytes to the host and wait for `stream`;
+ *   - nothing is allocated on behalf of the caller: scratch comes from the caller's
+ *     `workspace` (size from litho_abbe_workspace_bytes);
+ *   - pn = mask pixelNumber (even, 2..16384), N = FFT size from
+ *     Mask.calculateEpsilonN (power of two, pn <= N <= 16384).
+ */
+#ifndef LITHO_ABBE_H
+#define LITHO_ABBE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LITHO_OK 0
+#define LITHO_E_ARG (-1)        /* bad size / null pointer / unsupported (pn odd, N not 2^k) */
+#define LITHO_E_NSMALL (-2)     /* N < pn: the reference fails here too           */
+#define LITHO_E_WORKSPACE (-3)  /* workspace too small                                        */
+#define LITHO_E_HIP (-4)        /* a HIP runtime call failed; see litho_last_error()           */
+#define LITHO_E_INDEX (-5)      /* aberration vector of length 4 (pupil.py:91-92)   */
+
+/* Library version and the gfx target it was compiled for ("gfx950"). */
+int litho_version(void);
+const char *litho_target_arch(void);
+/* Text of the last HIP error seen by this thread ("" if none). */
+const char *litho_last_error(void);
+
+/* ---- FFT sizing: Mask.calculateEpsilonN / _nearest2SqInt (mask.py:63-72). Host only. */
+int litho_epsilon_n(double deltaK, double pixelSize, double wavelength,
+                    double *epsilon_host, int *N_host);
+
+/* ---- Source sampling: LightSource.generateAnnular (lightsource.py:34-50) and
+ * generateQuasar (lightsource.py:52-73).  kind 0 = annular, 1 = quasar.  Writes the int64
+ * 0/1 bitmap [pn,pn] the reference returns (fp16-exact sigma grid). */
+int litho_source_bitmap(int kind, double sigma_in, double sigma_out, int pn,
+                        double shift_x, double shift_y, int count, double rotation,
+                        int64_t *bitmap, void *stream);
+
+/* ---- imageformation.py:59 `(argwhere(lightsource) - pn//2).int()`: compacts any int64
+ * bitmap [pn,pn] (non-zero = lit) into int32 [S,2] (dy,dx) in row-major order.
+ * `shifts` must have room for pn*pn pairs (or `capacity` pairs; more lit pixels than
+ * that is LITHO_E_ARG).  Reads back: *count_host = S.  scratch: (pn+1) int32. */
+int litho_source_compact(const int64_t *bitmap, int pn, int32_t *shifts, int64_t capacity,
+                         int32_t *scratch, int64_t *count_host, void *stream);
+
+/* ---- Pupil: Pupil.generateWavefrontError / generatePupilFunction
+ * (pupil.py:32-38, 46-111).  coeffs_f16_host: J fp16 bit patterns (uint16) in OSA/ANSI
+ * order, as given by the caller, BEFORE the defocus rescale of coefficient 4; the
+ * rescaled vector is written back to coeffs_f16_host (the reference mutates its
+ * argument).  Outputs (either may be NULL): wavefront = fp16 W [pn,pn] as
+ * uint16 bit patterns, pupil = complex64 phi [pn,pn]. */
+int litho_pupil(uint16_t *coeffs_f16_host, int J, int pn, double NA, double wavelength,
+                uint16_t *wavefront, void *pupil, void *stream);
+
+/* ---- Workspace for the three calls below. */
+int litho_abbe_workspace_bytes(int pn, int N, size_t *bytes_host);
+
+/* ---- Abbe accumulation: the loop of abbeImage, imageformation.py:54-67.
+ *   out[p][q] += sum_{s<S} | E_{p,s}[q] |^2,   E = calculateFFTAerial(roll(P_p, shift_s), M)
+ * maskFT  complex64 [pn,pn]; pupil complex64 [planes,pn,pn] (planes >= 1: a through-focus
+ * stack sharing maskFT and the source list); shifts int32 [S,2] = (dy,dx) =
+ * (row - pn/2, col - pn/2); out fp32 [planes,pn,pn], accumulated into (the caller zeroes
+ * it, and all-reduces it across GPUs when the source list is sharded).
+ * Reads back 32 bytes once (pupil support box and shift extents) to plan the launch. */
+int litho_abbe_accumulate(const void *maskFT, const void *pupil, int planes,
+                          const int32_t *shifts, int64_t S, int pn, int N, float *out,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- Single-point field: calculateFFTAerial(pf, maskFFFT, pixelNumber, N)
+ * (imageformation.py:32-45).  field = complex64 [pn,pn].  Reads back 16 bytes. */
+int litho_abbe_field(const void *pf, const void *maskFT, int pn, int N, void *field,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- Post-process: imageformation.py:69-77 (abs, bilinear resample by 1/epsilon,
+ * zero pad; output size from litho_postprocess_size: 4096 -> 4094).
+ * raw fp32 [planes,pn,pn] -> out fp32 [planes,n_out,n_out]. */
+int litho_postprocess_size(int pn, double epsilon, int *n_out_host);
+int litho_postprocess(const float *raw, int planes, int pn, double epsilon, float *out,
+                      void *stream);
+
+/* ---- Mask spectrum pre-step: Mask._ffFraunhofer (mask.py:74-90).  geometry int16
+ * [pn,pn]; spectrum complex64 [pn,pn].  Uses the same workspace as the Abbe calls. */
+int litho_mask_spectrum(const int16_t *geometry, int pn, double epsilon, int N, void *spectrum,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- Introspection for bench.py / tests: what the last litho_abbe_accumulate on this
+ * thread planned.  fields: [0]=mode (0 pruned box, 1 general/wrapping), [1]=box row0,
+ * [2]=box col0, [3]=box rows, [4]=box cols, [5]=points per batch, [6]=x-pass launches,
+ * [7]=y-pass launches. */
+int litho_abbe_last_plan(int64_t fields_host[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LITHO_ABBE_H */

@@ -1,0 +1,315 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by importing the REAL reference
+(quarterwave0/LithographySimulator, mounted read-only at /root/reference) in the build
+container and running it on CPU.  Only the resulting data (.npz) is committed; the
+reference's source never enters this repository and never travels to the GPU box.
+
+    python tests/golden/make_golden.py            # regenerates every fixture
+
+Environment the committed fixtures were made with: torch 2.10.0+rocm7.0 (CPU), 8 threads.
+Fixture groups follow SURVEY.md section 8c (G1..G7).
+"""
+import hashlib
+import math
+import os
+import sys
+import zlib
+
+sys.dont_write_bytecode = True          # /root/reference is read-only
+REF = os.environ.get("LITHO_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+import contextlib
+import io
+
+import numpy as np
+import torch
+
+import imageformation as ref_if      # noqa: E402  (the reference)
+import lightsource as ref_ls         # noqa: E402
+import mask as ref_mask              # noqa: E402
+import pupil as ref_pupil            # noqa: E402
+
+from lithographysimulator_amd.synthetic import bernoulli_mask, lines_mask  # noqa: E402
+
+ref_if.Mask = ref_mask.Mask          # quirk Q1: abbeImage needs the global name
+CPU = torch.device("cpu")
+WL, NA, PS = 193.0, 0.7, 25
+DEMO_AB = [0, 0, 0.01, 0, 100, 0.01, 0, 0.01, 0.01, 0.01]     # imageformation.py:100
+QUASAR = (4, -math.pi / 8)                                      # imageformation.py:112
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def f16(v):
+    return torch.tensor(v, dtype=torch.float16)
+
+
+def source(kind, pn, sin, sout, sx=0.0, sy=0.0, count=4, rot=-math.pi / 8):
+    ls = quiet(ref_ls.LightSource, sin, sout, pn, NA, sx, sy, CPU)
+    return ls.generateAnnular() if kind == "annular" else ls.generateQuasar(count, rot)
+
+
+def pupil_fn(pn, ab):
+    t = None if ab is None else f16(ab)          # fresh tensor each call (quirk Q2)
+    return quiet(ref_pupil.Pupil, pn, WL, NA, t, CPU).generatePupilFunction()
+
+
+def wavefront(pn, ab):
+    t = f16([0]) if ab is None else f16(ab)
+    return ref_pupil.generateWavefrontError(t, pn, NA, WL, CPU).real.to(torch.float16)
+
+
+def shifts_of(bitmap, pn):
+    return (torch.argwhere(bitmap) - pn // 2).to(torch.int32)
+
+
+def raw_image(maskFT, pf, bitmap, N):
+    """imageformation.py:54-67 replayed with the reference's own functions, stopping before
+    the post-process, so kernel output and post-process are pinned separately (G7)."""
+    pn = maskFT.shape[0]
+    image = torch.zeros((pn, pn), dtype=torch.complex64)
+    sh = shifts_of(bitmap, pn)
+    for i in range(sh.shape[0]):
+        rolled = torch.roll(pf, shifts=(sh[i, 0], sh[i, 1]), dims=(0, 1))
+        image += torch.abs(ref_if.calculateFFTAerial(rolled, maskFT, pn, N)) ** 2
+    return image.real.clone()
+
+
+def subsample_bitmap(bitmap, K):
+    pts = torch.argwhere(bitmap)
+    S = pts.shape[0]
+    idx = (torch.arange(K) * S) // K
+    out = torch.zeros_like(bitmap)
+    out[pts[idx, 0], pts[idx, 1]] = 1
+    return out
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+                                 for k, v in arrays.items()})
+    print(f"  wrote {name}  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+SOURCE_CASES = {
+    "circ": dict(kind="annular", sin=0.0, sout=0.5),
+    "annular": dict(kind="annular", sin=0.4, sout=0.8),
+    "quasar": dict(kind="quasar", sin=0.4, sout=0.8),
+    "annular_shift": dict(kind="annular", sin=0.4, sout=0.8, sx=0.25, sy=-0.5),
+    "quasar3_oddshift": dict(kind="quasar", sin=0.3, sout=0.9, sx=0.2, sy=-0.1, count=3, rot=0.3),
+}
+
+
+def g1_sources():
+    print("G1 sources")
+    out = {}
+    for pn in (64, 256):
+        for name, kw in SOURCE_CASES.items():
+            out[f"shifts_{name}_{pn}"] = shifts_of(source(pn=pn, **kw), pn)
+    for pn in (1024, 2048, 4096):
+        for name, kw in SOURCE_CASES.items():
+            if pn == 4096 and name not in ("annular", "quasar", "circ"):
+                continue
+            bm = source(pn=pn, **kw).numpy().astype(np.uint8)
+            packed = np.packbits(bm)
+            out[f"count_{name}_{pn}"] = np.int64(bm.sum())
+            out[f"sha256_{name}_{pn}"] = np.frombuffer(hashlib.sha256(packed.tobytes()).digest(), dtype=np.uint8)
+            if pn <= 2048:
+                out[f"packed_{name}_{pn}"] = np.frombuffer(zlib.compress(packed.tobytes(), 9), dtype=np.uint8)
+    save("g1_sources.npz", **out)
+
+
+PUPIL_CASES = {
+    "ideal": None,
+    "defocus_p100": [0, 0, 0, 0, 100],
+    "defocus_m200": [0, 0, 0, 0, -200],
+    "defocus_p30": [0, 0, 0, 0, 30],
+    "demo": DEMO_AB,
+    "short3": [0.1, 0.2, 0.05],
+    "terms15": [0, 0, 0, 1, 3, 0, 0, 1, 0, 0, 0.02, 0.03, 0.01, 0.5, 0.2],
+}
+
+
+def g2_pupils():
+    print("G2 pupils")
+    out = {}
+    for pn in (64, 256):
+        for name, ab in PUPIL_CASES.items():
+            out[f"W_{name}_{pn}"] = wavefront(pn, ab).view(torch.int16)      # fp16 bit patterns
+            out[f"phi_{name}_{pn}"] = pupil_fn(pn, ab)
+    for pn in (1024, 2048):
+        for name in ("ideal", "defocus_p100", "demo"):
+            W = wavefront(pn, PUPIL_CASES[name])
+            phi = pupil_fn(pn, PUPIL_CASES[name])
+            out[f"Wsha_{name}_{pn}"] = np.frombuffer(hashlib.sha256(W.numpy().tobytes()).digest(), dtype=np.uint8)
+            out[f"Wsub_{name}_{pn}"] = W[::16, ::16].contiguous().view(torch.int16)
+            out[f"phisub_{name}_{pn}"] = phi[::16, ::16].contiguous()
+            out[f"nz_{name}_{pn}"] = np.int64((phi != 0).sum())
+            out[f"phisum_{name}_{pn}"] = phi.to(torch.complex128).sum().numpy()
+    save("g2_pupils.npz", **out)
+
+
+def mask_of(kind, pn):
+    if kind == "bern":
+        return bernoulli_mask(pn)
+    if kind == "lines":
+        return lines_mask(pn)
+    return None                                   # the reference's built-in 64x64 demo
+
+
+def g3_mask_spectra():
+    print("G3 mask spectra")
+    out = {}
+    for pn, ps, kinds in ((64, 25, ("demo", "bern", "lines")), (256, 25, ("bern", "lines")),
+                          (64, 48, ("bern",)), (64, 10, ("bern",)), (128, 25, ("bern",)),
+                          (96, 25, ("bern",))):
+        for kind in kinds:
+            mk = quiet(ref_mask.Mask, mask_of(kind, pn), ps, CPU)
+            eps, N = mk.calculateEpsilonN(mk.deltaK, ps, WL)
+            out[f"spec_{kind}_{pn}_ps{ps}"] = mk.fraunhofer(WL, True)
+            out[f"epsN_{kind}_{pn}_ps{ps}"] = np.array([eps, N], dtype=np.float64)
+    sizing = []
+    for pn in (64, 96, 100, 128, 256, 512, 1024, 2048, 4096, 8192):
+        for ps in (5, 10, 25, 48, 64, 65, 100):
+            mk = quiet(ref_mask.Mask, torch.zeros(2, 2), ps, CPU)
+            eps, N = mk.calculateEpsilonN(4 / pn, ps, WL)
+            sizing.append([pn, ps, eps, N])
+    out["sizing_table"] = np.array(sizing, dtype=np.float64)
+    save("g3_mask_spectra.npz", **out)
+
+
+def g4_fields():
+    print("G4 single-point fields")
+    out = {}
+    cases = [
+        ("demo64", None, 64, 25, DEMO_AB, [(0, 0), (5, -7), (-12, 12), (12, 0), (0, -12), (-3, -9), (25, -30)]),
+        ("bern256", "bern", 256, 25, None, [(0, 0), (51, -51), (-40, 13), (100, 90)]),
+        ("bern64_Neqpn", "bern", 64, 48, DEMO_AB, [(0, 0), (7, -11)]),
+        ("bern64_N4pn", "bern", 64, 10, DEMO_AB, [(0, 0), (-9, 4)]),
+        ("bern96", "bern", 96, 25, [0, 0, 0, 0, 50], [(0, 0), (10, -17)]),
+    ]
+    for tag, kind, pn, ps, ab, shifts in cases:
+        mk = quiet(ref_mask.Mask, mask_of(kind, pn) if kind else None, ps, CPU)
+        eps, N = mk.calculateEpsilonN(mk.deltaK, ps, WL)
+        mft = mk.fraunhofer(WL, True)
+        pf = pupil_fn(pn, ab)
+        out[f"{tag}_maskFT"] = mft
+        out[f"{tag}_pupil"] = pf
+        out[f"{tag}_N"] = np.int64(N)
+        out[f"{tag}_shifts"] = np.array(shifts, dtype=np.int32)
+        out[f"{tag}_fields"] = torch.stack([
+            ref_if.calculateFFTAerial(torch.roll(pf, shifts=s, dims=(0, 1)), mft, pn, N) for s in shifts])
+    save("g4_fields.npz", **out)
+
+
+def crop_stats(prefix, img, out, crop=128):
+    pn = img.shape[0]
+    c0 = pn // 2 - crop // 2
+    out[f"{prefix}_crop"] = img[c0:c0 + crop, c0:c0 + crop].contiguous()
+    out[f"{prefix}_rowsum"] = img.double().sum(1)
+    out[f"{prefix}_colsum"] = img.double().sum(0)
+    out[f"{prefix}_max"] = np.float64(img.max())
+    out[f"{prefix}_sum"] = np.float64(img.double().sum())
+    out[f"{prefix}_shape"] = np.array(img.shape, dtype=np.int64)
+
+
+def g5_images():
+    print("G5/G7 images")
+    out = {}
+    # demo 64^2, imageformation.py __main__ parameters
+    mk = quiet(ref_mask.Mask, None, PS, CPU)
+    mft = mk.fraunhofer(WL, True)
+    eps, N = mk.calculateEpsilonN(mk.deltaK, PS, WL)
+    bm = source("quasar", 64, 0.4, 0.8)
+    pf = pupil_fn(64, DEMO_AB)
+    out["demo64_final"] = ref_if.abbeImage(mk, mft, pf, bm, PS, mk.deltaK, WL, True, CPU)
+    out["demo64_raw"] = raw_image(mft, pf, bm, N)
+    # config 1: 256^2, circular sigma 0.5, ideal pupil, full source
+    for kind in ("bern", "lines"):
+        mk = quiet(ref_mask.Mask, mask_of(kind, 256), PS, CPU)
+        mft = mk.fraunhofer(WL, True)
+        eps, N = mk.calculateEpsilonN(mk.deltaK, PS, WL)
+        bm = source("annular", 256, 0.0, 0.5)
+        pf = pupil_fn(256, None)
+        out[f"cfg1_{kind}_final"] = ref_if.abbeImage(mk, mft, pf, bm, PS, mk.deltaK, WL, True, CPU)
+        out[f"cfg1_{kind}_raw"] = raw_image(mft, pf, bm, N)
+        print(f"   cfg1 {kind}: S={int(bm.sum())} sum={float(out[f'cfg1_{kind}_final'].sum()):.6e}")
+    # N == pn (pixelSize 48, eps < 1) and N == 4 pn (pixelSize 10) at 64^2, full annular source
+    for ps in (48, 10, 64):
+        mk = quiet(ref_mask.Mask, bernoulli_mask(64), ps, CPU)
+        mft = mk.fraunhofer(WL, True)
+        eps, N = mk.calculateEpsilonN(mk.deltaK, ps, WL)
+        bm = source("annular", 64, 0.4, 0.8)
+        pf = pupil_fn(64, DEMO_AB)
+        out[f"bern64_ps{ps}_final"] = ref_if.abbeImage(mk, mft, pf, bm, ps, mk.deltaK, WL, True, CPU)
+        out[f"bern64_ps{ps}_raw"] = raw_image(mft, pf, bm, N)
+    # non power-of-two mask size
+    mk = quiet(ref_mask.Mask, bernoulli_mask(96), PS, CPU)
+    mft = mk.fraunhofer(WL, True)
+    eps, N = mk.calculateEpsilonN(mk.deltaK, PS, WL)
+    bm = subsample_bitmap(source("annular", 96, 0.4, 0.8), 64)
+    pf = pupil_fn(96, [0, 0, 0, 0, 50])
+    out["bern96_final"] = ref_if.abbeImage(mk, mft, pf, bm, PS, mk.deltaK, WL, True, CPU)
+    out["bern96_raw"] = raw_image(mft, pf, bm, N)
+    out["bern96_bitmap"] = bm.to(torch.uint8)
+    # subsampled-source runs at the BASELINE sizes
+    for pn, K, skind, ab in ((1024, 16, "annular", [0, 0, 0, 0, 100]),
+                             (2048, 8, "quasar", DEMO_AB),
+                             (4096, 4, "annular", [0, 0, 0, 0, 100])):
+        mk = quiet(ref_mask.Mask, bernoulli_mask(pn), PS, CPU)
+        mft = mk.fraunhofer(WL, True)
+        eps, N = mk.calculateEpsilonN(mk.deltaK, PS, WL)
+        bm = subsample_bitmap(source(skind, pn, 0.4, 0.8), K)
+        pf = pupil_fn(pn, ab)
+        final = ref_if.abbeImage(mk, mft, pf, bm, PS, mk.deltaK, WL, True, CPU)
+        raw = raw_image(mft, pf, bm, N)
+        crop_stats(f"sub{pn}_final", final, out)
+        crop_stats(f"sub{pn}_raw", raw, out)
+        out[f"sub{pn}_shifts"] = shifts_of(bm, pn)
+        # spectrum pins at this size (the spectrum itself is too large to commit)
+        out[f"sub{pn}_maskFT_crop"] = mft[pn // 2 - 32:pn // 2 + 32, pn // 2 - 32:pn // 2 + 32].contiguous()
+        out[f"sub{pn}_maskFT_abs_sum"] = np.float64(mft.abs().double().sum())
+        print(f"   sub {pn}: K={K} shape={tuple(final.shape)} sum={float(final.double().sum()):.6e}")
+    save("g5_images.npz", **out)
+
+
+def g6_through_focus():
+    print("G6 through-focus")
+    out = {}
+    defocus = [-310 + 20 * k for k in range(32)]
+    out["defocus_nm"] = np.array(defocus, dtype=np.float64)
+    mk = quiet(ref_mask.Mask, None, PS, CPU)
+    mft = mk.fraunhofer(WL, True)
+    bm = source("quasar", 64, 0.4, 0.8)
+    planes = []
+    for d in defocus:
+        ab = list(DEMO_AB); ab[4] = d
+        planes.append(ref_if.abbeImage(mk, mft, pupil_fn(64, ab), bm, PS, mk.deltaK, WL, True, CPU))
+    out["stack64_final"] = torch.stack(planes)
+    mk = quiet(ref_mask.Mask, bernoulli_mask(256), PS, CPU)
+    mft = mk.fraunhofer(WL, True)
+    eps, N = mk.calculateEpsilonN(mk.deltaK, PS, WL)
+    bm = subsample_bitmap(source("quasar", 256, 0.4, 0.8), 64)
+    planes = []
+    for d in defocus[::4]:
+        ab = list(DEMO_AB); ab[4] = d
+        planes.append(raw_image(mft, pupil_fn(256, ab), bm, N))
+    out["stack256_raw"] = torch.stack(planes)
+    out["stack256_defocus_nm"] = np.array(defocus[::4], dtype=np.float64)
+    out["stack256_bitmap"] = bm.to(torch.uint8)
+    save("g6_through_focus.npz", **out)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    for g in which:
+        {"g1": g1_sources, "g2": g2_pupils, "g3": g3_mask_spectra, "g4": g4_fields,
+         "g5": g5_images, "g6": g6_through_focus}[g]()

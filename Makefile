@@ -1,0 +1,29 @@
+# Builds liblitho_abbe.so (hand-written HIP for gfx950 behind a C ABI) and the C oracle.
+HIPCC ?= hipcc
+ARCH ?= gfx950
+CSRC := lithographysimulator_amd/csrc
+OUT := lithographysimulator_amd/lib/liblitho_abbe.so
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
+
+all: $(OUT) oracle
+
+build/abbe_engine.o: $(CSRC)/abbe_engine.hip $(CSRC)/fft_core.hpp $(CSRC)/engine_common.hpp include/litho_abbe.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+build/optics.o: $(CSRC)/optics.hip $(CSRC)/engine_common.hpp include/litho_abbe.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -c $< -o $@
+build/common.o: $(CSRC)/common.hip $(CSRC)/engine_common.hpp include/litho_abbe.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(OUT): build/abbe_engine.o build/optics.o build/common.o
+	@mkdir -p lithographysimulator_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf build $(OUT)
+	$(MAKE) -C oracle clean
+.PHONY: all oracle clean

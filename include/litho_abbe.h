@@ -63,10 +63,16 @@ int litho_source_compact(const int64_t *bitmap, int pn, int32_t *shifts, int64_t
  * (pupil.py:32-38, 46-111).  coeffs_f16_host: J fp16 bit patterns (uint16) in OSA/ANSI
  * order, as given by the caller, BEFORE the defocus rescale of coefficient 4; the
  * rescaled vector is written back to coeffs_f16_host (the reference mutates its
- * argument).  Outputs (either may be NULL): wavefront = fp16 W [pn,pn] as
- * uint16 bit patterns, pupil = complex64 phi [pn,pn]. */
-int litho_pupil(uint16_t *coeffs_f16_host, int J, int pn, double NA, double wavelength,
+ * argument).  flags bit 0: skip that rescale (single-term generateZ,
+ * pupil.py:46-77).  Outputs (either may be NULL): wavefront = fp16 W [pn,pn] as uint16
+ * bit patterns, pupil = complex64 phi [pn,pn].  Waits for `stream` before returning
+ * (the term table is staged from host memory). */
+int litho_pupil(uint16_t *coeffs_f16_host, int J, int pn, double NA, double wavelength, int flags,
                 uint16_t *wavefront, void *pupil, void *stream);
+
+/* ---- generatePhi (pupil.py:102-111): pupil = exp(1j*2*pi*WE) for a complex64 wavefront
+ * error WE [pn,pn], zero where the fp16 radius exceeds 1. */
+int litho_pupil_phase(const void *wavefront_c64, int pn, void *pupil, void *stream);
 
 /* ---- Workspace for the three calls below. */
 int litho_abbe_workspace_bytes(int pn, int N, size_t *bytes_host);

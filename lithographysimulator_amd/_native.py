@@ -1,0 +1,134 @@
+"""ctypes binding of liblitho_abbe.so (C ABI: include/litho_abbe.h).
+
+The HIP library is the product: if it is missing, or no HIP device is visible, every
+compute entry point raises -- there is no CPU fallback."""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liblitho_abbe.so")
+
+LITHO_OK, E_ARG, E_NSMALL, E_WORKSPACE, E_HIP, E_INDEX = 0, -1, -2, -3, -4, -5
+_lib = None
+
+_SIGNATURES = {
+    "litho_version": (c_int, []),
+    "litho_target_arch": (c_char_p, []),
+    "litho_last_error": (c_char_p, []),
+    "litho_epsilon_n": (c_int, [c_double, c_double, c_double, POINTER(c_double), POINTER(c_int)]),
+    "litho_source_bitmap": (c_int, [c_int, c_double, c_double, c_int, c_double, c_double, c_int, c_double,
+                                    c_void_p, c_void_p]),
+    "litho_source_compact": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, POINTER(c_int64), c_void_p]),
+    "litho_pupil": (c_int, [c_void_p, c_int, c_int, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p]),
+    "litho_pupil_phase": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "litho_abbe_workspace_bytes": (c_int, [c_int, c_int, POINTER(c_size_t)]),
+    "litho_abbe_accumulate": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p,
+                                      c_void_p, c_size_t, c_void_p]),
+    "litho_abbe_field": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "litho_postprocess_size": (c_int, [c_int, c_double, POINTER(c_int)]),
+    "litho_postprocess": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p]),
+    "litho_mask_spectrum": (c_int, [c_void_p, c_int, c_double, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "litho_abbe_last_plan": (c_int, [POINTER(c_int64)]),
+}
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build the HIP extension first (`make` at the repository root or "
+                "`python -c 'import __graft_entry__ as g; g.build()'`).  There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def exported_symbols():
+    return list(_SIGNATURES)
+
+
+def check(rc, what):
+    if rc == LITHO_OK:
+        return
+    if rc == E_NSMALL:
+        # the reference dies with a tensor-size RuntimeError in this situation
+        raise RuntimeError(f"{what}: FFT size N is smaller than the mask pixelNumber; pixelSize is too "
+                           "large for this wavelength (the reference fails here as well)")
+    if rc == E_INDEX:
+        raise IndexError("index 4 is out of bounds for dimension 0 with size 4")
+    if rc == E_HIP:
+        raise RuntimeError(f"{what}: HIP error: {lib().litho_last_error().decode()}")
+    if rc == E_WORKSPACE:
+        raise RuntimeError(f"{what}: workspace too small")
+    raise ValueError(f"{what}: unsupported or invalid argument (pn must be even, 2..16384; N a power of two, "
+                     "16..16384)")
+
+
+def require_gpu(device):
+    if not isinstance(device, torch.device):
+        device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError(f"lithographysimulator_amd computes on an MI355X (HIP) device only; got device "
+                           f"'{device}'.  There is no CPU fallback.")
+    if not torch.cuda.is_available():
+        raise RuntimeError("no HIP device is visible to PyTorch-ROCm; there is no CPU fallback")
+    return device
+
+
+def pick_device(device, what):
+    """The reference's constructors accept anything and fall back mps > cuda > cpu with a
+    notice (mask.py:7-18 etc.).  Here: a torch.device is kept as is; otherwise the HIP device."""
+    if type(device) is torch.device:
+        return device
+    if torch.cuda.is_available():
+        d = torch.device("cuda", torch.cuda.current_device())
+        print(f"No device defined for {what}! Using {torch.cuda.get_device_name(d)}.")
+        return d
+    print(f"No device defined for {what}! No HIP device is visible; compute calls will fail.")
+    return torch.device("cpu")
+
+
+def stream_ptr(device):
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr())
+
+
+_workspaces = {}
+
+
+def workspace(device, pn, N):
+    """Scratch buffer for the Abbe / field / mask-spectrum calls, cached per (device, pn, N)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), pn, N)
+    ws = _workspaces.get(key)
+    if ws is None:
+        nbytes = c_size_t(0)
+        check(lib().litho_abbe_workspace_bytes(pn, N, ctypes.byref(nbytes)), "litho_abbe_workspace_bytes")
+        _workspaces.clear()                       # keep one live workspace: they are up to ~1.5 GiB
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def epsilon_n(deltaK, pixelSize, wavelength):
+    eps, N = c_double(0), c_int(0)
+    check(lib().litho_epsilon_n(float(deltaK), float(pixelSize), float(wavelength), ctypes.byref(eps),
+                                ctypes.byref(N)), "litho_epsilon_n")
+    return eps.value, N.value
+
+
+def last_plan():
+    arr = (c_int64 * 8)()
+    lib().litho_abbe_last_plan(arr)
+    keys = ("general", "box_row0", "box_col0", "box_rows", "box_cols", "batch", "xpass_launches", "ypass_launches")
+    return dict(zip(keys, list(arr)))

@@ -1,0 +1,177 @@
+// fft_core.hpp -- per-line FFT engine for gfx950 (wave64, LDS exchange, register radix-16).
+//
+// One "line" is a length-N complex DFT (N = 2^LOG2N, 16 <= N <= 16384) computed by
+// T = N/16 threads that each hold 16 points in registers.  N = R1 * 16^P16 with
+// R1 in {1,2,4,8}: an optional leading radix-R1 pass (no twiddles) followed by P16
+// radix-16 Stockham passes; between passes the points are exchanged through LDS.
+// Both on input and on output thread t owns the natural-order indices n = t + T*e,
+// e = 0..15, so consecutive threads touch consecutive samples (coalesced global I/O).
+//
+// The Abbe path needs a CENTRED transform, out[u] = sum_k in[k] w^(k u) with k and u
+// running over windows around zero; since w^N = 1 that is the plain DFT on indices
+// taken mod N, and the callers just map n -> k (or u) and skip what is outside their
+// window (zero padding is never materialised, discarded outputs are never written).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace litho {
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+// cos(2 pi m / 32), m = 0..16; sin follows from cos(2 pi (8 - m) / 32).
+static constexpr double W32C[17] = {
+    1, 0.98078528040323043, 0.92387953251128674, 0.83146961230254524, 0.70710678118654757,
+    0.55557023301960229, 0.38268343236508984, 0.19509032201612833, 0.0,
+    -0.19509032201612819, -0.38268343236508973, -0.55557023301960196, -0.70710678118654746,
+    -0.83146961230254535, -0.92387953251128674, -0.98078528040323043, -1};
+
+template <int I, int END, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < END) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, END>(f);
+    }
+}
+
+// v * exp(SIGN * 2 pi i * M / R), M in [0, R/2), compile-time specialised.
+template <int R, int M, int SIGN>
+__device__ __forceinline__ float2 mul_root(float2 v) {
+    if constexpr (M == 0) {
+        return v;
+    } else if constexpr (4 * M == R) {           // multiply by (SIGN) i
+        return SIGN > 0 ? make_float2(-v.y, v.x) : make_float2(v.y, -v.x);
+    } else if constexpr (8 * M == R) {           // (1 + SIGN i)/sqrt2
+        constexpr float h = 0.70710678118654752f;
+        return SIGN > 0 ? make_float2((v.x - v.y) * h, (v.x + v.y) * h)
+                        : make_float2((v.x + v.y) * h, (v.y - v.x) * h);
+    } else if constexpr (8 * M == 3 * R) {       // (-1 + SIGN i)/sqrt2
+        constexpr float h = 0.70710678118654752f;
+        return SIGN > 0 ? make_float2(-(v.x + v.y) * h, (v.x - v.y) * h)
+                        : make_float2((v.y - v.x) * h, -(v.x + v.y) * h);
+    } else {
+        constexpr int idx = M * (32 / R);                       // angle = 2 pi idx / 32, idx in (0,16)
+        constexpr float wr = (float)W32C[idx];
+        constexpr float wi = (float)(SIGN * (idx <= 8 ? W32C[8 - idx] : W32C[idx - 8]));
+        return make_float2(fmaf(v.x, wr, -v.y * wi), fmaf(v.x, wi, v.y * wr));
+    }
+}
+
+// In-register DFT of R points: x[m] <- sum_r x[r] exp(SIGN 2 pi i r m / R), natural order.
+template <int R, int SIGN>
+struct Dft {
+    __device__ static __forceinline__ void run(float2 (&x)[R]) {
+        float2 e[R / 2], o[R / 2];
+        static_for<0, R / 2>([&](auto i) { e[i] = x[2 * i]; o[i] = x[2 * i + 1]; });
+        Dft<R / 2, SIGN>::run(e);
+        Dft<R / 2, SIGN>::run(o);
+        static_for<0, R / 2>([&](auto m) {
+            float2 t = mul_root<R, decltype(m)::value, SIGN>(o[m]);
+            x[m] = cadd(e[m], t);
+            x[m + R / 2] = csub(e[m], t);
+        });
+    }
+};
+template <int SIGN>
+struct Dft<1, SIGN> {
+    __device__ static __forceinline__ void run(float2 (&)[1]) {}
+};
+template <int SIGN>
+struct Dft<2, SIGN> {
+    __device__ static __forceinline__ void run(float2 (&x)[2]) {
+        float2 a = x[0], b = x[1];
+        x[0] = cadd(a, b);
+        x[1] = csub(a, b);
+    }
+};
+
+__device__ __forceinline__ int lds_pad(int i) { return i + (i >> 4); }   // one extra slot per 16
+
+template <int LOG2N, int SIGN>
+struct LineFFT {
+    static_assert(LOG2N >= 4 && LOG2N <= 14, "16 <= N <= 16384");
+    static constexpr int N = 1 << LOG2N;
+    static constexpr int E = 16;                   // points per thread
+    static constexpr int T = N / E;                // threads per line
+    static constexpr int P16 = LOG2N / 4;          // radix-16 passes
+    static constexpr int R1 = N >> (4 * P16);      // leading radix (1 = none)
+    static constexpr int B1 = E / R1;              // leading-pass butterflies per thread
+    static constexpr int EXCH = P16 - 1 + (R1 > 1 ? 1 : 0);   // LDS exchanges per transform
+    static constexpr int LDS_LINE = N + N / 16;    // float2 slots per buffer per line
+    // Radix-16 pass p has Ns = R1 * 16^p; it needs twiddles iff Ns > 1.
+    static constexpr int NTW = P16 - (R1 == 1 ? 1 : 0);
+
+    struct Twiddles {
+        float2 w[NTW > 0 ? NTW : 1][15];
+    };
+
+    // table[n] = exp(+2 pi i n / N); SIGN < 0 conjugates on the fly.
+    __device__ static __forceinline__ void load_twiddles(Twiddles& tw, const float2* __restrict__ table, int t) {
+        int ns = (R1 == 1) ? 16 : R1;
+#pragma unroll
+        for (int p = 0; p < NTW; ++p) {
+            const int k = t & (ns - 1);
+            const int step = k * (N / (16 * ns));
+#pragma unroll
+            for (int r = 1; r < 16; ++r) {
+                float2 w = table[step * r];
+                if (SIGN < 0) w.y = -w.y;
+                tw.w[p][r - 1] = w;
+            }
+            ns *= 16;
+        }
+    }
+
+    // x[e] holds sample n = t + T*e on entry and output bin n = t + T*e on exit.
+    // lds: this line's two exchange buffers (2 * LDS_LINE float2) when NBUF == 2, one when NBUF == 1.
+    // `flip` alternates buffers across consecutive exchanges (also across calls).
+    template <int NBUF>
+    __device__ static __forceinline__ void run(float2 (&x)[E], const Twiddles& tw, float2* lds, int t, int& flip) {
+        int ns = 1;
+        if constexpr (R1 > 1) {
+            float2* buf = lds + (NBUF == 2 ? (flip & 1) * LDS_LINE : 0);
+            if constexpr (NBUF == 1) __syncthreads();
+            static_for<0, B1>([&](auto b) {
+                float2 v[R1];
+                static_for<0, R1>([&](auto r) { v[r] = x[b + B1 * r]; });
+                Dft<R1, SIGN>::run(v);
+                const int j = t + T * b;
+                static_for<0, R1>([&](auto m) { buf[lds_pad(j * R1 + m)] = v[m]; });
+            });
+            __syncthreads();
+            static_for<0, E>([&](auto r) { x[r] = buf[lds_pad(t + r * T)]; });
+            flip ^= 1;
+            ns = R1;
+        }
+        static_for<0, P16>([&](auto p) {
+            constexpr int twi = p - (R1 == 1 ? 1 : 0);
+            if constexpr (twi >= 0) {
+                static_for<1, 16>([&](auto r) { x[r] = cmul(x[r], tw.w[twi][r - 1]); });
+            }
+            Dft<16, SIGN>::run(x);
+            if constexpr (p < P16 - 1) {
+                float2* buf = lds + (NBUF == 2 ? (flip & 1) * LDS_LINE : 0);
+                if constexpr (NBUF == 1) __syncthreads();
+                const int k = t & (ns - 1);
+                const int base = (t - k) * 16 + k;
+                static_for<0, 16>([&](auto m) { buf[lds_pad(base + m * ns)] = x[m]; });
+                __syncthreads();
+                static_for<0, 16>([&](auto r) { x[r] = buf[lds_pad(t + r * T)]; });
+                flip ^= 1;
+                ns *= 16;
+            }
+        });
+    }
+};
+
+// Map a natural-order index n in [0,N) onto the centred window [lo, hi): returns the
+// representative (n or n-N) and whether it falls inside.  Needs -N/2 <= lo, hi <= N/2 + 1.
+__device__ __forceinline__ bool centred_index(int n, int N, int lo, int hi, int& k) {
+    k = (n >= hi) ? n - N : n;
+    return (k >= lo) && (k < hi);
+}
+
+}  // namespace litho

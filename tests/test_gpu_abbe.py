@@ -1,0 +1,265 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (ctypes), against the
+golden vectors captured from the reference and against the CPU oracle on seeded inputs.
+Run on the MI355X box with  python -m pytest tests -m gpu."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import (DEMO_AB, NA, PS, TOL_FIELD, TOL_IMAGE_L2, TOL_IMAGE_MAX, WL, crop_center, f16, rel_l2,
+                     rel_max, subsample_bitmap)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def L():
+    import lithographysimulator_amd as L
+    from lithographysimulator_amd import _native as nat
+    assert nat.lib().litho_target_arch() == b"gfx950"
+    return L
+
+
+def O():
+    from oracle import abbe_oracle
+    return abbe_oracle
+
+
+# ------------------------------------------------------------------ single-point fields (G4)
+@pytest.mark.parametrize("tag", ["demo64", "bern256", "bern64_Neqpn", "bern64_N4pn", "bern96"])
+def test_fields_vs_golden(golden, L, dev, tag):
+    g = golden("g4_fields.npz")
+    mft = torch.from_numpy(g[f"{tag}_maskFT"]).to(dev)
+    pf = torch.from_numpy(g[f"{tag}_pupil"]).to(dev)
+    N = int(g[f"{tag}_N"]); pn = mft.shape[0]
+    for s, ref in zip(g[f"{tag}_shifts"], g[f"{tag}_fields"]):
+        rolled = torch.roll(pf, shifts=(int(s[0]), int(s[1])), dims=(0, 1))
+        got = L.calculateFFTAerial(rolled, mft, pn, N).cpu()
+        assert rel_max(got, torch.from_numpy(ref)) < TOL_FIELD, (tag, s)
+
+
+def test_field_full_support_pupil(L, dev):
+    """A pupil with no zeros at all (full pn x pn support) exercises the un-pruned window."""
+    o = O()
+    gen = torch.Generator().manual_seed(7)
+    pn, N = 64, 128
+    pf = torch.complex(torch.randn(pn, pn, generator=gen), torch.randn(pn, pn, generator=gen))
+    mft = torch.complex(torch.randn(pn, pn, generator=gen), torch.randn(pn, pn, generator=gen))
+    got = L.calculateFFTAerial(pf.to(dev), mft.to(dev), pn, N).cpu()
+    assert rel_max(got, o.field_closed_form(pf, mft, 0, 0, N)) < TOL_FIELD
+
+
+def test_field_zero_pupil(L, dev):
+    pn, N = 64, 128
+    z = torch.zeros(pn, pn, dtype=torch.complex64, device=dev)
+    m = torch.ones(pn, pn, dtype=torch.complex64, device=dev)
+    assert float(L.calculateFFTAerial(z, m, pn, N).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("log2n", range(4, 15))
+def test_every_fft_size_impulse_and_random(L, dev, log2n):
+    """Each FFT plan N = 16..16384: random dense data on a small window against the closed form."""
+    o = O()
+    N = 1 << log2n
+    pn = min(N, 32)
+    gen = torch.Generator().manual_seed(log2n)
+    pf = torch.complex(torch.randn(pn, pn, generator=gen), torch.randn(pn, pn, generator=gen))
+    mft = torch.complex(torch.randn(pn, pn, generator=gen), torch.randn(pn, pn, generator=gen))
+    got = L.calculateFFTAerial(pf.to(dev), mft.to(dev), pn, N).cpu()
+    assert rel_max(got, o.field_closed_form(pf, mft, 0, 0, N)) < TOL_FIELD
+
+
+# ------------------------------------------------------------------ images (G5 / G7)
+def _raw(L, dev, mft, pf, shifts, N):
+    return L.abbeIntensity(mft.to(dev), pf.to(dev), shifts.to(dev), N)
+
+
+def test_demo_image_vs_golden(golden, L, dev):
+    g = golden("g5_images.npz")
+    mask = L.Mask(device=dev, pixelSize=PS)
+    mft = mask.fraunhofer(WL, True)
+    ls = L.LightSource(sigmaIn=0.4, sigmaOut=0.8, device=dev)
+    bm = ls.generateQuasar(4, -math.pi / 8)
+    pf = L.Pupil(mask.pixelNumber, WL, ls.NA, f16(DEMO_AB), device=dev).generatePupilFunction()
+    img = L.abbeImage(mask, mft, pf, bm, mask.pixelSize, mask.deltaK, WL, True, dev).cpu()
+    ref = torch.from_numpy(g["demo64_final"])
+    assert img.shape == ref.shape and img.dtype == torch.float32
+    assert rel_max(img, ref) < TOL_IMAGE_MAX and rel_l2(img, ref) < TOL_IMAGE_L2
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    raw = L.abbeIntensity(mft, pf, L.sourceShifts(bm, 64), N).cpu()
+    assert rel_max(raw, g["demo64_raw"]) < TOL_IMAGE_MAX and rel_l2(raw, g["demo64_raw"]) < TOL_IMAGE_L2
+
+
+@pytest.mark.parametrize("kind", ["bern", "lines"])
+def test_config1_vs_golden(golden, L, dev, kind):
+    """BASELINE config 1 (256^2, circular sigma 0.5, ideal pupil, S = 3233), end to end."""
+    from lithographysimulator_amd.synthetic import bernoulli_mask, lines_mask
+    g = golden("g5_images.npz")
+    geo = bernoulli_mask(256) if kind == "bern" else lines_mask(256)
+    mask = L.Mask(geo, PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    bm = L.LightSource(0.0, 0.5, 256, NA, device=dev).generateAnnular()
+    pf = L.Pupil(256, WL, NA, None, dev).generatePupilFunction()
+    img = L.abbeImage(mask, mft, pf, bm, PS, mask.deltaK, WL, True, dev).cpu()
+    assert rel_max(img, g[f"cfg1_{kind}_final"]) < TOL_IMAGE_MAX
+    assert rel_l2(img, g[f"cfg1_{kind}_final"]) < TOL_IMAGE_L2
+
+
+@pytest.mark.parametrize("ps", [48, 10, 64])
+def test_other_fft_ratios_vs_golden(golden, L, dev, ps):
+    """N = pn (pixelSize 48 and 64, epsilon < 1 and > 1) and N = 4 pn (pixelSize 10)."""
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    g = golden("g5_images.npz")
+    mask = L.Mask(bernoulli_mask(64), ps, dev)
+    mft = mask.fraunhofer(WL, True)
+    bm = L.LightSource(0.4, 0.8, 64, NA, device=dev).generateAnnular()
+    pf = L.Pupil(64, WL, NA, f16(DEMO_AB), dev).generatePupilFunction()
+    img = L.abbeImage(mask, mft, pf, bm, ps, mask.deltaK, WL, True, dev).cpu()
+    ref = torch.from_numpy(g[f"bern64_ps{ps}_final"])
+    assert img.shape == ref.shape
+    assert rel_max(img, ref) < TOL_IMAGE_MAX
+
+
+def test_non_power_of_two_mask(golden, L, dev):
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    g = golden("g5_images.npz")
+    mask = L.Mask(bernoulli_mask(96), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    bm = torch.from_numpy(g["bern96_bitmap"]).to(torch.int64).to(dev)
+    pf = L.Pupil(96, WL, NA, f16([0, 0, 0, 0, 50]), dev).generatePupilFunction()
+    img = L.abbeImage(mask, mft, pf, bm, PS, mask.deltaK, WL, True, dev).cpu()
+    assert rel_max(img, g["bern96_final"]) < TOL_IMAGE_MAX
+
+
+def test_n_smaller_than_mask_raises(L, dev):
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    mask = L.Mask(bernoulli_mask(64), 100, dev)          # pixelSize 100 -> N = 32 < 64
+    with pytest.raises(RuntimeError):
+        mask.fraunhofer(WL, True)
+
+
+def test_wrapping_shifts_general_mode(golden, L, dev):
+    """Shifts that push the pupil support across the grid edge: torch.roll wraps
+    (imageformation.py:63); the engine must switch to its modular (general) path."""
+    from lithographysimulator_amd import _native as nat
+    o = O()
+    g = golden("g4_fields.npz")
+    mft = torch.from_numpy(g["demo64_maskFT"]); pf = torch.from_numpy(g["demo64_pupil"])
+    N = int(g["demo64_N"])
+    shifts = torch.tensor([[25, -30], [-31, 31], [0, 0], [17, 20], [-32, -32]], dtype=torch.int32)
+    got = _raw(L, dev, mft, pf, shifts, N).cpu()
+    assert nat.last_plan()["general"] == 1
+    ref = o.abbe_raw_f64(mft, pf, shifts, N)
+    assert rel_max(got, ref) < TOL_IMAGE_MAX
+    chain = o.abbe_raw(mft, pf, shifts, N)
+    assert rel_max(got, chain) < TOL_IMAGE_MAX
+
+
+def test_general_and_pruned_modes_agree(golden, L, dev, monkeypatch):
+    g = golden("g4_fields.npz")
+    mft = torch.from_numpy(g["bern256_maskFT"]); pf = torch.from_numpy(g["bern256_pupil"])
+    N = int(g["bern256_N"])
+    shifts = torch.tensor([[0, 0], [51, -51], [-40, 13], [10, 3]], dtype=torch.int32)
+    a = _raw(L, dev, mft, pf, shifts, N).cpu()
+    monkeypatch.setenv("LITHO_ABBE_FORCE_GENERAL", "1")
+    b = _raw(L, dev, mft, pf, shifts, N).cpu()
+    assert rel_max(a, b) < 5e-6
+
+
+@pytest.mark.parametrize("pn,K,skind,ab", [(1024, 16, "annular", [0, 0, 0, 0, 100]),
+                                           (2048, 8, "quasar", DEMO_AB),
+                                           (4096, 4, "annular", [0, 0, 0, 0, 100])])
+def test_subsampled_baseline_sizes_vs_golden(golden, L, dev, pn, K, skind, ab):
+    """BASELINE configs 2/3/4 geometry with K source points strided through the real list."""
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    g = golden("g5_images.npz")
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    c0 = pn // 2 - 32
+    assert rel_max(mft[c0:c0 + 64, c0:c0 + 64].cpu(), g[f"sub{pn}_maskFT_crop"]) < 2e-6
+    ls = L.LightSource(0.4, 0.8, pn, NA, device=dev)
+    full = ls.generateAnnular() if skind == "annular" else ls.generateQuasar(4, -math.pi / 8)
+    bm = subsample_bitmap(full.cpu(), K).to(dev)
+    assert np.array_equal(L.sourceShifts(bm, pn).cpu().numpy(), g[f"sub{pn}_shifts"])
+    pf = L.Pupil(pn, WL, NA, f16(ab), dev).generatePupilFunction()
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    raw = L.abbeIntensity(mft, pf, L.sourceShifts(bm, pn), N).cpu()
+    assert rel_max(crop_center(raw), g[f"sub{pn}_raw_crop"]) < TOL_IMAGE_MAX
+    assert np.allclose(raw.double().sum(1).numpy(), g[f"sub{pn}_raw_rowsum"], rtol=2e-5)
+    assert np.allclose(raw.double().sum(0).numpy(), g[f"sub{pn}_raw_colsum"], rtol=2e-5)
+    assert abs(float(raw.max()) / float(g[f"sub{pn}_raw_max"]) - 1) < 2e-5
+    img = L.abbeImage(mask, mft, pf, bm, PS, mask.deltaK, WL, True, dev).cpu()
+    assert tuple(img.shape) == tuple(g[f"sub{pn}_final_shape"])          # 4096 -> 4094 (Q5)
+    assert rel_max(crop_center(img), g[f"sub{pn}_final_crop"]) < TOL_IMAGE_MAX
+    assert abs(float(img.double().sum()) / float(g[f"sub{pn}_final_sum"]) - 1) < 2e-5
+
+
+# ------------------------------------------------------------------ through-focus stack (G6)
+def test_through_focus_stack(golden, L, dev):
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    g = golden("g6_through_focus.npz")
+    mask = L.Mask(bernoulli_mask(256), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    bm = torch.from_numpy(g["stack256_bitmap"]).to(torch.int64).to(dev)
+    stack = L.throughFocusPupils(256, WL, NA, f16(DEMO_AB), [float(d) for d in g["stack256_defocus_nm"]], dev)
+    raw = L.abbeIntensity(mft, stack, L.sourceShifts(bm, 256), N).cpu()
+    assert raw.shape == g["stack256_raw"].shape
+    for k in range(raw.shape[0]):
+        assert rel_max(raw[k], g["stack256_raw"][k]) < TOL_IMAGE_MAX, k
+
+
+def test_through_focus_demo_planes(golden, L, dev):
+    g = golden("g6_through_focus.npz")
+    mask = L.Mask(device=dev, pixelSize=PS)
+    mft = mask.fraunhofer(WL, True)
+    bm = L.LightSource(0.4, 0.8, device=dev).generateQuasar(4, -math.pi / 8)
+    for k in (0, 7, 16, 31):
+        ab = list(DEMO_AB); ab[4] = float(g["defocus_nm"][k])
+        pf = L.Pupil(64, WL, NA, f16(ab), dev).generatePupilFunction()
+        img = L.abbeImage(mask, mft, pf, bm, PS, mask.deltaK, WL, True, dev).cpu()
+        assert rel_max(img, g["stack64_final"][k]) < TOL_IMAGE_MAX
+
+
+# ------------------------------------------------------------------ size-independent properties at full size
+def test_properties_2048(L, dev):
+    """At BASELINE config 3's full grid (2048^2, N = 4096): the Abbe sum is additive over any
+    partition of the source list and batch-size independent; |alpha M|^2 scales the image by
+    |alpha|^2; an empty list adds nothing; accumulation into a non-zero buffer adds."""
+    import os
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    pn = 2048
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    pf = L.Pupil(pn, WL, NA, f16(DEMO_AB), dev).generatePupilFunction()
+    bm = L.LightSource(0.4, 0.8, pn, NA, device=dev).generateQuasar(4, -math.pi / 8)
+    sh = L.sourceShifts(bm, pn)
+    assert sh.shape[0] == 198108                                     # SURVEY 8a [ran]
+    sel = sh[(torch.arange(40, device=dev) * sh.shape[0]) // 40]
+    whole = L.abbeIntensity(mft, pf, sel, N)
+    parts = L.abbeIntensity(mft, pf, sel[:13], N)
+    L.abbeIntensity(mft, pf, sel[13:], N, out=parts)                 # accumulate into a live buffer
+    assert rel_max(parts.cpu(), whole.cpu()) < 2e-6
+    os.environ["LITHO_ABBE_BATCH"] = "7"
+    try:
+        rebatched = L.abbeIntensity(mft, pf, sel, N)
+    finally:
+        del os.environ["LITHO_ABBE_BATCH"]
+    assert rel_max(rebatched.cpu(), whole.cpu()) < 2e-6
+    scaled = L.abbeIntensity(mft * (0.5 + 0.25j), pf, sel, N)
+    assert rel_max(scaled.cpu(), whole.cpu() * abs(0.5 + 0.25j) ** 2) < 2e-6
+    assert float(L.abbeIntensity(mft, pf, sel[:0], N).abs().max()) == 0.0
+    # Parseval on one source point: sum over the FULL N-period of |E|^2 is N^2 sum |A|^2; the kept
+    # centre window can only hold part of it.
+    one = L.abbeIntensity(mft, pf, sel[:1], N)
+    dy, dx = [int(v) for v in sel[0].tolist()]
+    A = torch.roll(pf, shifts=(dy, dx), dims=(0, 1)) * mft
+    assert float(one.double().sum()) <= float(N) ** 2 * float((A.abs().double() ** 2).sum()) * (1 + 1e-5)

@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Abbe source-points x image-pixels per second on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4]
+
+One "step" = one complete abbeImage call (source-list compaction, Abbe accumulation over
+every source point of the configuration, all-reduce when N > 1, post-process) on synthetic
+inputs that are resident in HBM when the timed region starts.  Default workload = BASELINE
+config 3, the one the roofline target is quoted on: 2048x2048 bernoulli mask, quasar source
+sigma 0.4-0.8 (S = 198,108), 10-term Zernike-aberrated pupil.  With N > 1 (launched by
+torch.distributed.run, one rank per GPU) the source list is split into N contiguous shards and
+the partial intensities are summed by ONE RCCL all-reduce: total work is fixed -> "strong".
+
+Rank 0 prints one JSON line (contract in the task statement) carrying `roofline` (dominant
+kernel, HIP-event timed live) and, at N = 1, `cpu_baseline` (the oracle's torch-CPU op chain,
+i.e. a port of the reference loop, on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import math
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WL, NA, PS = 193.0, 0.7, 25
+DEMO_AB = [0, 0, 0.01, 0, 100, 0.01, 0, 0.01, 0.01, 0.01]
+WORKLOADS = {
+    # name: (pn, source kind, aberrations, description)
+    "cfg2": (1024, "annular", [0, 0, 0, 0, 100], "1024x1024 bernoulli mask, annular 0.4-0.8, defocus-only pupil"),
+    "cfg3": (2048, "quasar", DEMO_AB, "2048x2048 bernoulli mask, quasar(4,-pi/8) 0.4-0.8, 10-term Zernike pupil"),
+    "cfg4": (4096, "annular", [0, 0, 0, 0, 100], "4096x4096 bernoulli mask, annular 0.4-0.8, defocus-only pupil"),
+}
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+# Algorithmic bytes per source-point*pixel: 40 for the fused pipeline =
+# x-pass 24 (read mask window 8 + pupil window 8, write intermediate 8) + y-pass 16 (read
+# intermediate 8, read-modify-write intensity 8).
+ALGO_BYTES = {"xpass": 24.0, "ypass": 16.0}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N with N > 1 must be launched by torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    import torch.distributed as dist
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    group = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)          # "nccl" is RCCL on ROCm
+        group = dist.group.WORLD
+
+    import lithographysimulator_amd as L
+    from lithographysimulator_amd import _native as nat
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+
+    pn, skind, ab, desc = WORKLOADS[args.workload]
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    maskFT = mask.fraunhofer(WL, True)
+    epsilon, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    ls = L.LightSource(0.4, 0.8, pn, NA, device=dev)
+    bitmap = ls.generateAnnular() if skind == "annular" else ls.generateQuasar(4, -math.pi / 8)
+    pupil = L.Pupil(pn, WL, NA, torch.tensor(ab, dtype=torch.float16), dev).generatePupilFunction()
+    S = int(bitmap.sum())
+    torch.cuda.synchronize()
+
+    def step():
+        return L.abbeImage(mask, maskFT, pupil, bitmap, PS, mask.deltaK, WL, True, dev, group=group)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        image = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    units = float(S) * pn * pn                                   # source-point*pixels per step, whole job
+    value = units * args.steps / elapsed
+
+    # ---- roofline leg: HIP-event time of each kernel class over one more (untimed) step of this rank's shard
+    nat.set_profiling(True)
+    step()
+    torch.cuda.synchronize()
+    prof = nat.last_profile()
+    plan = nat.last_plan()
+    nat.set_profiling(False)
+    kern = {}
+    for k in ("xpass", "ypass"):
+        launches = max(1, prof[f"{k}_launches"])
+        pts = prof[f"{k}_points"]
+        avg_ms = prof[f"{k}_ms"] / launches
+        algo_bytes_per_launch = ALGO_BYTES[k] * pn * pn * pts / launches
+        kern[k] = {"avg_launch_ms": avg_ms, "launches": launches, "points_per_launch": pts / launches,
+                   "algorithmic_bytes_per_launch": algo_bytes_per_launch,
+                   "achieved_GBs": algo_bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
+                   "total_ms": prof[f"{k}_ms"]}
+    dom = max(kern, key=lambda k: kern[k]["total_ms"])
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")       # PMC-derived HBM bytes per launch (rocprofv3 --pmc)
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
+        except Exception:
+            traffic = None
+    both_ms = kern["xpass"]["total_ms"] + kern["ypass"]["total_ms"]
+    roofline = {"bound": "hbm", "kernel": "k_ypass_acc" if dom == "ypass" else "k_xpass_abbe",
+                "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": kern[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
+                "avg_launch_ms": kern[dom]["avg_launch_ms"],
+                "algorithmic_bytes_per_launch": kern[dom]["algorithmic_bytes_per_launch"],
+                "pipeline_40B": {"achieved": 40.0 * pn * pn * prof["ypass_points"] / (both_ms * 1e-3) / 1e9 if both_ms else 0.0,
+                                 "frac": 40.0 * pn * pn * prof["ypass_points"] / (both_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if both_ms else 0.0,
+                                 "note": "effective: 40 B/unit model over x-pass + y-pass kernel time; real HBM bytes are lower (see traffic)"},
+                "kernels": kern}
+
+    out = {"metric": "Abbe source-points x image-pixels per second", "value": value, "unit": "source-pt*px/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 (complex64)",
+           "data": "synthetic",
+           "config": {"workload": f"BASELINE {args.workload}: {desc}", "pn": pn, "fft_n": N, "source_points": S,
+                      "points_per_rank": math.ceil(S / world), "pixel_size": PS, "wavelength": WL, "NA": NA,
+                      "parallelism": f"source-point shards x{world}, one all-reduce" if world > 1 else "single GPU",
+                      "plan": plan, "image_shape": list(image.shape)},
+           "roofline": roofline}
+
+    # ---- CPU baseline leg: the oracle's op-chain port of the reference loop, rank 0, N = 1 only
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import abbe_oracle as O
+        torch.set_num_threads(os.cpu_count() or 1)
+        K = {1024: 16, 2048: 8, 4096: 4}.get(pn, 8)
+        shifts = L.sourceShifts(bitmap, pn)
+        sel = shifts[(torch.arange(K, device=dev) * S) // K].cpu()
+        m_cpu, p_cpu = maskFT.cpu(), pupil.cpu()
+        O.abbe_raw(m_cpu, p_cpu, sel[:1], N)                        # warm-up
+        times = []
+        for _ in range(3):
+            c0 = time.perf_counter()
+            ref_raw = O.abbe_raw(m_cpu, p_cpu, sel, N)
+            times.append(time.perf_counter() - c0)
+        tmed = statistics.median(times)
+        gpu_raw = L.abbeIntensity(maskFT, pupil, sel.to(dev), N).cpu()
+        parity = float((gpu_raw - ref_raw).abs().max() / ref_raw.max())
+        out["cpu_baseline"] = {"value": K * pn * pn / tmed, "unit": "source-pt*px/s", "cores": torch.get_num_threads(),
+                               "kind": "port",
+                               "sample": f"{K} source points strided through the {S}-point list, full {pn}x{pn} grid, "
+                                         f"1 warm-up + 3 reps, median {tmed:.2f} s; oracle/abbe_oracle.py abbe_raw "
+                                         "(torch-CPU roll/mul/pad/fftshift/ifft2/ifftshift/crop/abs2/add)",
+                               "gpu_vs_cpu_rel_to_max": parity}
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -111,6 +111,13 @@ int litho_mask_spectrum(const int16_t *geometry, int pn, double epsilon, int N, 
  * [7]=y-pass launches. */
 int litho_abbe_last_plan(int64_t fields_host[8]);
 
+/* ---- Per-kernel timing for bench.py: when on, litho_abbe_accumulate brackets every x-pass
+ * and y-pass launch with HIP events recorded on `stream` (at most 4096 launches per call)
+ * and waits for the last one before returning.  fields: [0]=x-pass total ms, [1]=x-pass
+ * launches, [2]=source points those launches covered, [3..5]=the same for the y-pass. */
+int litho_abbe_set_profiling(int on);
+int litho_abbe_last_profile(double fields_host[8]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,8 @@ _SIGNATURES = {
     "litho_postprocess": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p]),
     "litho_mask_spectrum": (c_int, [c_void_p, c_int, c_double, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "litho_abbe_last_plan": (c_int, [POINTER(c_int64)]),
+    "litho_abbe_set_profiling": (c_int, [c_int]),
+    "litho_abbe_last_profile": (c_int, [POINTER(c_double)]),
 }
 
 
@@ -132,3 +134,14 @@ def last_plan():
     lib().litho_abbe_last_plan(arr)
     keys = ("general", "box_row0", "box_col0", "box_rows", "box_cols", "batch", "xpass_launches", "ypass_launches")
     return dict(zip(keys, list(arr)))
+
+
+def set_profiling(on: bool):
+    lib().litho_abbe_set_profiling(1 if on else 0)
+
+
+def last_profile():
+    arr = (c_double * 8)()
+    lib().litho_abbe_last_profile(arr)
+    return {"xpass_ms": arr[0], "xpass_launches": int(arr[1]), "xpass_points": int(arr[2]),
+            "ypass_ms": arr[3], "ypass_launches": int(arr[4]), "ypass_points": int(arr[5])}

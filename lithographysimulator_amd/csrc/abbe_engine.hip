@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "../../include/litho_abbe.h"
 #include "fft_core.hpp"
@@ -479,6 +480,12 @@ static int env_int(const char* name, int dflt)
 
 static thread_local int64_t g_last_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
+// Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's
+// roofline leg).  Off by default: the events serialise nothing but cost host time.
+static thread_local int g_profiling = 0;
+static thread_local double g_profile[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // x ms, x launches, x points, y ms, y launches, y points, -, -
+struct EventPair { hipEvent_t a, b; int kind; int nb; };
+
 template <int LOG2N, int SIGN, typename Loader>
 static hipError_t launch_xpass(const Loader& ld, float2* T, const float2* tw, const PassGeom& g, int nb, hipStream_t st)
 {
@@ -615,25 +622,56 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     const size_t slab_plane = (size_t)g.nt * 4 * pn;
     const int l2 = ilog2(N);
     int64_t nx = 0, ny = 0;
+    std::vector<EventPair> events;
+    const size_t max_events = 4096;
+    auto ev_begin = [&](int kind, int nb) {
+        if (!g_profiling || events.size() >= max_events) return;
+        EventPair e{nullptr, nullptr, kind, nb};
+        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+        (void)hipEventRecord(e.a, st);
+        events.push_back(e);
+    };
+    auto ev_end = [&]() {
+        if (!g_profiling || events.empty() || events.size() > max_events) return;
+        (void)hipEventRecord(events.back().b, st);
+    };
 
     for (int p = 0; p < planes; ++p) {
         const float2* Pp = P + (size_t)p * pn * pn;
         HIP_TRY(hipMemsetAsync(w.slab, 0, (size_t)G * slab_plane * sizeof(float), st));
         for (int64_t s0 = 0; s0 < S; s0 += bs) {
             const int nb = (int)((S - s0 < bs) ? (S - s0) : bs);
+            ev_begin(0, nb);
             if (general) {
                 AbbeLoader ld{Pp, M, shifts + 2 * s0, nullptr, nullptr, 0, 0};
                 LITHO_DISPATCH_LOG2N(l2, HIP_TRY((launch_xpass<L2, +1, AbbeLoader>(ld, w.T, w.twtab, g, nb, st))));
             } else {
                 LITHO_DISPATCH_LOG2N(l2, HIP_TRY((launch_xpass_abbe<L2>(Pp, M, shifts + 2 * s0, w.T, w.twtab, g, nb, st))));
             }
+            ev_end();
             const int Geff = nb < G ? nb : G;
+            ev_begin(1, nb);
             LITHO_DISPATCH_LOG2N(l2, HIP_TRY((launch_ypass_acc<L2>(w.T, w.slab, w.twtab, g, nb, Geff, st))));
+            ev_end();
             ++nx; ++ny;
         }
         hipLaunchKernelGGL(k_slab_reduce, dim3((pn + 31) / 32, (pn + 31) / 32), dim3(256), 0, st,
                            w.slab, out + (size_t)p * pn * pn, pn, g.nt * 4, G);
         HIP_TRY(hipGetLastError());
+    }
+    if (g_profiling) {
+        for (int i = 0; i < 8; ++i) g_profile[i] = 0;
+        if (!events.empty()) (void)hipEventSynchronize(events.back().b);
+        for (auto& e : events) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+                g_profile[e.kind * 3 + 0] += ms;
+                g_profile[e.kind * 3 + 1] += 1;
+                g_profile[e.kind * 3 + 2] += e.nb;
+            }
+            (void)hipEventDestroy(e.a);
+            (void)hipEventDestroy(e.b);
+        }
     }
     g_last_plan[0] = general; g_last_plan[1] = r0; g_last_plan[2] = c0; g_last_plan[3] = h;
     g_last_plan[4] = wdt; g_last_plan[5] = bs; g_last_plan[6] = nx; g_last_plan[7] = ny;
@@ -742,6 +780,19 @@ int litho_mask_spectrum(const int16_t* geometry, int pn, double epsilon, int N, 
 {
     return litho::mask_spectrum(geometry, pn, epsilon, N, (float2*)spectrum, workspace, workspace_bytes,
                                 (hipStream_t)stream);
+}
+
+int litho_abbe_set_profiling(int on)
+{
+    litho::g_profiling = on ? 1 : 0;
+    return LITHO_OK;
+}
+
+int litho_abbe_last_profile(double fields_host[8])
+{
+    if (!fields_host) return LITHO_E_ARG;
+    memcpy(fields_host, litho::g_profile, sizeof(litho::g_profile));
+    return LITHO_OK;
 }
 
 int litho_abbe_last_plan(int64_t fields_host[8])

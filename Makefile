@@ -4,10 +4,17 @@ ARCH ?= gfx950
 CSRC := lithographysimulator_amd/csrc
 OUT := lithographysimulator_amd/lib/liblitho_abbe.so
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
+# FFT kernels: no signed zeros, so that literal-zero input slots fold through the butterflies.
+FFTFLAGS := -fno-signed-zeros
+INST := $(patsubst $(CSRC)/%.hip,build/%.o,$(wildcard $(CSRC)/inst_*.hip))
+HDRS := $(CSRC)/fft_core.hpp $(CSRC)/engine_kernels.hpp $(CSRC)/engine_common.hpp include/litho_abbe.h
 
 all: $(OUT) oracle
 
-build/abbe_engine.o: $(CSRC)/abbe_engine.hip $(CSRC)/fft_core.hpp $(CSRC)/engine_common.hpp include/litho_abbe.h
+build/inst_%.o: $(CSRC)/inst_%.hip $(HDRS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) $(FFTFLAGS) -c $< -o $@
+build/abbe_engine.o: $(CSRC)/abbe_engine.hip $(HDRS)
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 build/optics.o: $(CSRC)/optics.hip $(CSRC)/engine_common.hpp include/litho_abbe.h
@@ -16,7 +23,7 @@ build/optics.o: $(CSRC)/optics.hip $(CSRC)/engine_common.hpp include/litho_abbe.
 build/common.o: $(CSRC)/common.hip $(CSRC)/engine_common.hpp include/litho_abbe.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-$(OUT): build/abbe_engine.o build/optics.o build/common.o
+$(OUT): build/abbe_engine.o build/optics.o build/common.o $(INST)
 	@mkdir -p lithographysimulator_amd/lib
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 

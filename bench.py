@@ -156,7 +156,9 @@ def main():
     # ---- CPU baseline leg: the oracle's op-chain port of the reference loop, rank 0, N = 1 only
     if world == 1 and not args.no_cpu_baseline:
         from oracle import abbe_oracle as O
-        torch.set_num_threads(os.cpu_count() or 1)
+        # 32 threads is the fastest setting for this op chain on the GPU box's 2 x EPYC 9575F (256 hw threads:
+        # 8 -> 2.1e7, 32 -> 2.6e7, 256 -> 1.6e6 pt*px/s; scripts/cpu_threads_probe.py), so that is the baseline.
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
         K = {1024: 16, 2048: 8, 4096: 4}.get(pn, 8)
         shifts = L.sourceShifts(bitmap, pn)
         sel = shifts[(torch.arange(K, device=dev) * S) // K].cpu()

@@ -108,7 +108,8 @@ int litho_mask_spectrum(const int16_t *geometry, int pn, double epsilon, int N, 
 /* ---- Introspection for bench.py / tests: what the last litho_abbe_accumulate on this
  * thread planned.  fields: [0]=mode (0 pruned box, 1 general/wrapping), [1]=box row0,
  * [2]=box col0, [3]=box rows, [4]=box cols, [5]=points per batch, [6]=x-pass launches,
- * [7]=y-pass launches. */
+ * [7]=kernel variant (-1 generic, else
+ * log2(N/pn) of the pruned specialisation). */
 int litho_abbe_last_plan(int64_t fields_host[8]);
 
 /* ---- Per-kernel timing for bench.py: when on, litho_abbe_accumulate brackets every x-pass

@@ -9,7 +9,7 @@ from ctypes import POINTER, c_char_p, c_double, c_int, c_int64, c_size_t, c_void
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liblitho_abbe.so")
+LIB_PATH = os.environ.get("LITHO_ABBE_LIB") or os.path.join(_HERE, "lib", "liblitho_abbe.so")
 
 LITHO_OK, E_ARG, E_NSMALL, E_WORKSPACE, E_HIP, E_INDEX = 0, -1, -2, -3, -4, -5
 _lib = None
@@ -132,7 +132,7 @@ def epsilon_n(deltaK, pixelSize, wavelength):
 def last_plan():
     arr = (c_int64 * 8)()
     lib().litho_abbe_last_plan(arr)
-    keys = ("general", "box_row0", "box_col0", "box_rows", "box_cols", "batch", "xpass_launches", "ypass_launches")
+    keys = ("general", "box_row0", "box_col0", "box_rows", "box_cols", "batch", "launches", "variant")
     return dict(zip(keys, list(arr)))
 
 

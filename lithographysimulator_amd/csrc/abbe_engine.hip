@@ -31,310 +31,10 @@
 #include <vector>
 
 #include "../../include/litho_abbe.h"
-#include "fft_core.hpp"
 #include "engine_common.hpp"
+#include "engine_kernels.hpp"
 
 namespace litho {
-
-// ----------------------------------------------------------------------------------
-// geometry shared by the pass kernels
-// ----------------------------------------------------------------------------------
-struct PassGeom {
-    int pn, c, N;
-    int nt;                 // column tiles of 4 (ceil(pn/4))
-    int kx0, kx1;           // x-pass: valid input window [kx0,kx1) in centred coordinates
-    int ky0, ky1;           // y-pass: valid input window = rows of T; a = k - ky0
-    int rows;               // number of T rows (= ky1 - ky0)
-    int general;            // 1: roll stays on P, modular gather (wrapping shifts)
-    long long t_point;      // float2 elements of T per source point = nt*rows*4
-};
-
-template <int LOG2N>
-struct Launch {
-    using F = LineFFT<LOG2N, +1>;
-    static constexpr int L = (F::T >= 64) ? 1 : 64 / F::T;       // lines per workgroup
-    static constexpr int THREADS = F::T * L;
-    static constexpr int NBUF = (LOG2N <= 12) ? 2 : 1;
-    static constexpr size_t LDS_BYTES = sizeof(float2) * (size_t)L * NBUF * F::LDS_LINE;
-    // launch_bounds second argument = waves per SIMD we want resident: two workgroups per CU
-    // up to N = 4096 (256 threads each), one above.
-    static constexpr int WAVES = (THREADS / 256 > 0 ? THREADS / 256 : 1) * (LOG2N <= 12 ? 2 : 1);
-};
-
-// ----------------------------------------------------------------------------------
-// buffer addressing: 32-bit offsets, and the hardware range check is the zero-padding
-// predicate (an offset >= num_records loads 0 / drops the store).
-// ----------------------------------------------------------------------------------
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-static constexpr unsigned BUF_OOB = 0xFFFF0000u;
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, size_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(unsigned)bytes, 0x00020000);
-}
-__device__ __forceinline__ float2 buf_load_c64(__amdgpu_buffer_rsrc_t r, unsigned off) {
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
-    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
-}
-__device__ __forceinline__ void buf_store_c64(__amdgpu_buffer_rsrc_t r, unsigned off, float2 v) {
-    u32x2 w;
-    w.x = __float_as_uint(v.x);
-    w.y = __float_as_uint(v.y);
-    __builtin_amdgcn_raw_buffer_store_b64(w, r, off, 0, 0);
-}
-
-// ----------------------------------------------------------------------------------
-// x-pass, pruned mode (no wrapping shift): A = P[box] * M[box + shift]
-// ----------------------------------------------------------------------------------
-template <int LOG2N>
-__global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void k_xpass_abbe(
-    const float2* __restrict__ P, const float2* __restrict__ M, const int* __restrict__ shifts,
-    float2* __restrict__ Tbuf, const float2* __restrict__ twtab, PassGeom g)
-{
-    using F = LineFFT<LOG2N, +1>;
-    using LC = Launch<LOG2N>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2* smem = reinterpret_cast<float2*>(smem_raw);
-    const int lt = threadIdx.x % F::T, lg = threadIdx.x / F::T;
-    float2* lds = smem + (size_t)lg * LC::NBUF * F::LDS_LINE;
-
-    typename F::Twiddles tw;
-    F::load_twiddles(tw, twtab, lt);
-
-    const int s = blockIdx.y;
-    const int dy = shifts[2 * s], dx = shifts[2 * s + 1];
-    const int a = blockIdx.x * LC::L + lg;
-    const bool active = a < g.rows;
-    const int r = g.ky0 + g.c + a;                            // row of P inside its support box
-    const unsigned prow = (unsigned)r * g.pn + g.c;           // element offset of centred column 0
-    const unsigned mrow = (unsigned)(r + dy) * g.pn + g.c + dx;   // same window of M moved by the shift
-    const size_t plane_bytes = (size_t)g.pn * g.pn * sizeof(float2);
-    const __amdgpu_buffer_rsrc_t rP = make_rsrc(P, plane_bytes);
-    const __amdgpu_buffer_rsrc_t rM = make_rsrc(M, plane_bytes);
-
-    float2 x[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        int k;
-        const bool ok = centred_index(lt + F::T * e, F::N, g.kx0, g.kx1, k) && active;
-        const float2 pv = buf_load_c64(rP, ok ? (prow + k) * 8u : BUF_OOB);
-        const float2 mv = buf_load_c64(rM, ok ? (mrow + k) * 8u : BUF_OOB);
-        x[e] = cmul(pv, mv);
-    }
-    int flip = 0;
-    F::template run<LC::NBUF>(x, tw, lds, lt, flip);
-
-    const __amdgpu_buffer_rsrc_t rT = make_rsrc(Tbuf + (size_t)s * g.t_point, (size_t)g.t_point * sizeof(float2));
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        int u;
-        const bool ok = centred_index(lt + F::T * m, F::N, -g.c, g.pn - g.c, u) && active;
-        const unsigned q = (unsigned)(u + g.c);
-        buf_store_c64(rT, ok ? (((q >> 2) * g.rows + a) * 4u + (q & 3u)) * 8u : BUF_OOB, x[m]);
-    }
-}
-
-// ----------------------------------------------------------------------------------
-// generic x-pass (any loader): rows -> T[s][tile][row][4]
-// ----------------------------------------------------------------------------------
-template <int LOG2N, int SIGN, typename Loader>
-__global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void k_xpass(
-    Loader ld, float2* __restrict__ Tbuf, const float2* __restrict__ twtab, PassGeom g)
-{
-    using F = LineFFT<LOG2N, SIGN>;
-    using LC = Launch<LOG2N>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2* smem = reinterpret_cast<float2*>(smem_raw);
-    const int lt = threadIdx.x % F::T, lg = threadIdx.x / F::T;
-    float2* lds = smem + (size_t)lg * LC::NBUF * F::LDS_LINE;
-
-    typename F::Twiddles tw;
-    F::load_twiddles(tw, twtab, lt);
-
-    const int s = blockIdx.y;
-    const int a = blockIdx.x * LC::L + lg;
-    const bool active = a < g.rows;
-    ld.begin_line(s, active ? a : 0, g);
-
-    float2 x[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        int k;
-        const bool ok = centred_index(lt + F::T * e, F::N, g.kx0, g.kx1, k) && active;
-        x[e] = ok ? ld.load(k, g) : make_float2(0.f, 0.f);
-    }
-    int flip = 0;
-    F::template run<LC::NBUF>(x, tw, lds, lt, flip);
-
-    float2* trow = Tbuf + (size_t)s * g.t_point + (size_t)a * 4;
-    const size_t tile_stride = (size_t)g.rows * 4;
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        int u;
-        if (centred_index(lt + F::T * m, F::N, -g.c, g.pn - g.c, u) && active) {
-            const int q = u + g.c;
-            trow[(size_t)(q >> 2) * tile_stride + (q & 3)] = x[m];
-        }
-    }
-}
-
-// Loader: Abbe product P*M for source point s (imageformation.py:34 and :63).
-struct AbbeLoader {
-    const float2* P;
-    const float2* M;
-    const int* shifts;       // (dy,dx) pairs of this batch
-    const float2* prow;
-    const float2* mrow;
-    int dx, pr_general;
-    __device__ __forceinline__ void begin_line(int s, int a, const PassGeom& g) {
-        const int dy = shifts[2 * s];
-        dx = shifts[2 * s + 1];
-        if (!g.general) {
-            const int r = g.ky0 + g.c + a;                  // row of P (support box row)
-            prow = P + (size_t)r * g.pn;
-            mrow = M + (size_t)(r + dy) * g.pn + dx;        // same window of M, moved by the shift
-        } else {
-            int r = (a - dy) % g.pn;                        // torch.roll: A[i] = P[(i - d) mod pn]
-            if (r < 0) r += g.pn;
-            prow = P + (size_t)r * g.pn;
-            mrow = M + (size_t)a * g.pn;
-        }
-    }
-    __device__ __forceinline__ float2 load(int k, const PassGeom& g) const {
-        const int col = k + g.c;
-        if (!g.general) return cmul(prow[col], mrow[col]);
-        int pc = (col - dx) % g.pn;
-        if (pc < 0) pc += g.pn;
-        return cmul(prow[pc], mrow[col]);
-    }
-};
-
-// Loader: a real image (the bilinearly scaled mask, mask.py:76-81).  Line a / sample k of the
-// padded N x N frame map to img[a + off][k - kx0 + off]; the zero padding (or, when the
-// scaled mask is larger than N, the crop) is expressed by the window and `off` alone.
-struct RealImageLoader {
-    const float* img;        // [n,n]
-    int n, off;
-    const float* row;
-    __device__ __forceinline__ void begin_line(int, int a, const PassGeom&) { row = img + (size_t)(a + off) * n + off; }
-    __device__ __forceinline__ float2 load(int k, const PassGeom& g) const {
-        return make_float2(row[k - g.kx0], 0.f);
-    }
-};
-
-// ----------------------------------------------------------------------------------
-// y-pass with |E|^2 accumulation in registers over the batch
-// ----------------------------------------------------------------------------------
-// RL = log2(N/pn) when pn is a power of two (valid output bins are then the same 16>>RL
-// registers for every thread), -1 = any even pn (all 16 kept, predicated at the flush).
-template <int RL>
-struct OutSel {
-    static constexpr int NV = (RL < 0) ? 16 : (16 >> RL);
-    __device__ static constexpr int m_of(int iv) { return (RL <= 0) ? iv : (iv < NV / 2 ? iv : 16 - NV + iv); }
-};
-
-template <int LOG2N, int RL>
-__global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void k_ypass_acc(
-    const float2* __restrict__ Tbuf, float* __restrict__ slab, const float2* __restrict__ twtab,
-    PassGeom g, int nb, int G)
-{
-    using F = LineFFT<LOG2N, +1>;
-    using LC = Launch<LOG2N>;
-    using OS = OutSel<RL>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2* smem = reinterpret_cast<float2*>(smem_raw);
-    const int lt = threadIdx.x % F::T, lg = threadIdx.x / F::T;
-    float2* lds = smem + (size_t)lg * LC::NBUF * F::LDS_LINE;
-
-    typename F::Twiddles tw;
-    F::load_twiddles(tw, twtab, lt);
-
-    const int tile = blockIdx.x * LC::L + lg;
-    const bool active = tile < g.nt;
-    const int grp = blockIdx.y;
-
-    float acc[4][OS::NV];
-#pragma unroll
-    for (int cidx = 0; cidx < 4; ++cidx)
-#pragma unroll
-        for (int iv = 0; iv < OS::NV; ++iv) acc[cidx][iv] = 0.f;
-
-    // per-thread input map: sample e <-> byte offset of T row a_e inside this tile (or out of range)
-    unsigned voff[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        int k;
-        const bool ok = centred_index(lt + F::T * e, F::N, g.ky0, g.ky1, k) && active;
-        voff[e] = ok ? ((unsigned)tile * g.rows + (unsigned)(k - g.ky0)) * 32u : BUF_OOB;
-    }
-
-    int flip = 0;
-    for (int s = grp; s < nb; s += G) {
-        const __amdgpu_buffer_rsrc_t rT =
-            make_rsrc(Tbuf + (size_t)s * g.t_point, (size_t)g.t_point * sizeof(float2));
-#pragma unroll
-        for (int cidx = 0; cidx < 4; ++cidx) {
-            float2 x[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) x[e] = buf_load_c64(rT, voff[e] + cidx * 8u);
-            F::template run<LC::NBUF>(x, tw, lds, lt, flip);
-#pragma unroll
-            for (int iv = 0; iv < OS::NV; ++iv) {
-                const float2 v = x[OS::m_of(iv)];
-                acc[cidx][iv] = fmaf(v.x, v.x, fmaf(v.y, v.y, acc[cidx][iv]));
-            }
-        }
-    }
-
-    if (!active) return;
-    // flush into this group's private slab, laid out [G][qx][qy] (qy contiguous -> coalesced)
-#pragma unroll
-    for (int cidx = 0; cidx < 4; ++cidx) {
-        const int qx = tile * 4 + cidx;
-        if (qx >= g.pn) continue;
-        float* srow = slab + ((size_t)grp * g.nt * 4 + qx) * g.pn;
-#pragma unroll
-        for (int iv = 0; iv < OS::NV; ++iv) {
-            int u;
-            if (centred_index(lt + F::T * OS::m_of(iv), F::N, -g.c, g.pn - g.c, u)) srow[u + g.c] += acc[cidx][iv];
-        }
-    }
-}
-
-// y-pass that writes the complex field instead (calculateFFTAerial, mask spectrum).
-template <int LOG2N, int SIGN>
-__global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void k_ypass_field(
-    const float2* __restrict__ Tbuf, float2* __restrict__ field, const float2* __restrict__ twtab, PassGeom g)
-{
-    using F = LineFFT<LOG2N, SIGN>;
-    using LC = Launch<LOG2N>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2* smem = reinterpret_cast<float2*>(smem_raw);
-    const int lt = threadIdx.x % F::T, lg = threadIdx.x / F::T;
-    float2* lds = smem + (size_t)lg * LC::NBUF * F::LDS_LINE;
-    typename F::Twiddles tw;
-    F::load_twiddles(tw, twtab, lt);
-    const int tile = blockIdx.x * LC::L + lg;
-    const bool active = tile < g.nt;
-    const float2* tt = Tbuf + (size_t)(active ? tile : 0) * g.rows * 4;
-    int flip = 0;
-    for (int cidx = 0; cidx < 4; ++cidx) {
-        float2 x[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            int k;
-            const bool ok = centred_index(lt + F::T * e, F::N, g.ky0, g.ky1, k) && active;
-            x[e] = ok ? tt[(size_t)(k - g.ky0) * 4 + cidx] : make_float2(0.f, 0.f);
-        }
-        F::template run<LC::NBUF>(x, tw, lds, lt, flip);
-        const int qx = tile * 4 + cidx;
-        if (!active || qx >= g.pn) continue;
-#pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            int u;
-            if (centred_index(lt + F::T * m, F::N, -g.c, g.pn - g.c, u)) field[(size_t)(u + g.c) * g.pn + qx] = x[m];
-        }
-    }
-}
 
 // ----------------------------------------------------------------------------------
 // small helpers: twiddle table, planning, slab reduction
@@ -484,86 +184,33 @@ static thread_local int64_t g_last_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 // roofline leg).  Off by default: the events serialise nothing but cost host time.
 static thread_local int g_profiling = 0;
 static thread_local double g_profile[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // x ms, x launches, x points, y ms, y launches, y points, -, -
-struct EventPair { hipEvent_t a, b; int kind; int nb; };
+struct Mark { hipEvent_t ev; int kind; int nb; };   // kind: -1 start, 0 after an x-pass, 1 after a y-pass
 
-template <int LOG2N, int SIGN, typename Loader>
-static hipError_t launch_xpass(const Loader& ld, float2* T, const float2* tw, const PassGeom& g, int nb, hipStream_t st)
-{
-    using LC = Launch<LOG2N>;
-    dim3 grid((g.rows + LC::L - 1) / LC::L, nb);
-    auto kern = k_xpass<LOG2N, SIGN, Loader>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LC::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, dim3(LC::THREADS), LC::LDS_BYTES, st, ld, T, tw, g);
-    return hipGetLastError();
-}
+const SizeOps* size_ops_4(); const SizeOps* size_ops_5(); const SizeOps* size_ops_6(); const SizeOps* size_ops_7();
+const SizeOps* size_ops_8(); const SizeOps* size_ops_9(); const SizeOps* size_ops_10(); const SizeOps* size_ops_11();
+const SizeOps* size_ops_12(); const SizeOps* size_ops_13(); const SizeOps* size_ops_14();
 
-template <int LOG2N>
-static hipError_t launch_xpass_abbe(const float2* P, const float2* M, const int* shifts, float2* T, const float2* tw,
-                                    const PassGeom& g, int nb, hipStream_t st)
+const SizeOps* size_ops(int log2n)
 {
-    using LC = Launch<LOG2N>;
-    dim3 grid((g.rows + LC::L - 1) / LC::L, nb);
-    auto kern = k_xpass_abbe<LOG2N>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LC::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, dim3(LC::THREADS), LC::LDS_BYTES, st, P, M, shifts, T, tw, g);
-    return hipGetLastError();
-}
-
-template <int LOG2N, int RL>
-static hipError_t launch_ypass_acc_rl(const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb, int G, hipStream_t st)
-{
-    using LC = Launch<LOG2N>;
-    dim3 grid((g.nt + LC::L - 1) / LC::L, G);
-    auto kern = k_ypass_acc<LOG2N, RL>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LC::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, dim3(LC::THREADS), LC::LDS_BYTES, st, T, slab, tw, g, nb, G);
-    return hipGetLastError();
-}
-
-template <int LOG2N>
-static hipError_t launch_ypass_acc(const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb, int G, hipStream_t st)
-{
-    const bool pow2 = (g.pn & (g.pn - 1)) == 0;
-    const int rl = pow2 ? (LOG2N - ilog2(g.pn)) : -1;
-    switch (rl) {
-        case 0: return launch_ypass_acc_rl<LOG2N, 0>(T, slab, tw, g, nb, G, st);
-        case 1: return launch_ypass_acc_rl<LOG2N, 1>(T, slab, tw, g, nb, G, st);
-        case 2: return launch_ypass_acc_rl<LOG2N, 2>(T, slab, tw, g, nb, G, st);
-        case 3: return launch_ypass_acc_rl<LOG2N, 3>(T, slab, tw, g, nb, G, st);
-        default: return launch_ypass_acc_rl<LOG2N, -1>(T, slab, tw, g, nb, G, st);
+    switch (log2n) {
+        case 4: return size_ops_4();   case 5: return size_ops_5();   case 6: return size_ops_6();
+        case 7: return size_ops_7();   case 8: return size_ops_8();   case 9: return size_ops_9();
+        case 10: return size_ops_10(); case 11: return size_ops_11(); case 12: return size_ops_12();
+        case 13: return size_ops_13(); case 14: return size_ops_14();
+        default: return nullptr;
     }
 }
 
-template <int LOG2N, int SIGN>
-static hipError_t launch_ypass_field(const float2* T, float2* field, const float2* tw, const PassGeom& g, hipStream_t st)
+// Which specialised kernel variant fits this geometry (-1 = generic).
+static int pick_variant(const PassGeom& g)
 {
-    using LC = Launch<LOG2N>;
-    dim3 grid((g.nt + LC::L - 1) / LC::L);
-    auto kern = k_ypass_field<LOG2N, SIGN>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LC::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, dim3(LC::THREADS), LC::LDS_BYTES, st, T, field, tw, g);
-    return hipGetLastError();
+    if (g.general || (g.pn & (g.pn - 1))) return -1;
+    const int rl = ilog2(g.N) - ilog2(g.pn);
+    if (rl < 0 || rl > 2) return -1;
+    const unsigned nat = natural_in_mask(rl);
+    if ((g.xmask & ~nat) || (g.ymask & ~nat)) return -1;
+    return env_int("LITHO_ABBE_FORCE_GENERIC", 0) ? -1 : rl;
 }
-
-#define LITHO_DISPATCH_LOG2N(l2, CALL)                                         \
-    switch (l2) {                                                              \
-        case 4: { constexpr int L2 = 4; CALL; } break;                         \
-        case 5: { constexpr int L2 = 5; CALL; } break;                         \
-        case 6: { constexpr int L2 = 6; CALL; } break;                         \
-        case 7: { constexpr int L2 = 7; CALL; } break;                         \
-        case 8: { constexpr int L2 = 8; CALL; } break;                         \
-        case 9: { constexpr int L2 = 9; CALL; } break;                         \
-        case 10: { constexpr int L2 = 10; CALL; } break;                       \
-        case 11: { constexpr int L2 = 11; CALL; } break;                       \
-        case 12: { constexpr int L2 = 12; CALL; } break;                       \
-        case 13: { constexpr int L2 = 13; CALL; } break;                       \
-        case 14: { constexpr int L2 = 14; CALL; } break;                       \
-        default: return LITHO_E_ARG;                                           \
-    }
 
 // Reads the 8 plan words back (one small synchronising copy).
 static int read_plan(const Workspace& w, int host[8], hipStream_t st)
@@ -573,12 +220,28 @@ static int read_plan(const Workspace& w, int host[8], hipStream_t st)
     return LITHO_OK;
 }
 
+// bit e of the mask: some thread t of a line has its slot e (sample n = t + T*e) inside [lo,hi)
+static unsigned slot_mask(int N, int lo, int hi)
+{
+    const int T = N / 16;
+    unsigned m = 0;
+    for (int e = 0; e < 16; ++e)
+        for (int t = 0; t < T; ++t) {
+            const int n = t + T * e;
+            const int k = (n >= hi) ? n - N : n;
+            if (k >= lo && k < hi) { m |= 1u << e; break; }
+        }
+    return m;
+}
+
 static void make_geom(PassGeom& g, int pn, int N, int r0, int c0, int h, int wdt, int general)
 {
     g.pn = pn; g.c = pn / 2; g.N = N; g.nt = (pn + 3) / 4;
     g.kx0 = c0 - g.c; g.kx1 = c0 + wdt - g.c;
     g.ky0 = r0 - g.c; g.ky1 = r0 + h - g.c;
     g.rows = h; g.general = general;
+    g.xmask = slot_mask(N, g.kx0, g.kx1);
+    g.ymask = slot_mask(N, g.ky0, g.ky1);
     g.t_point = (long long)g.nt * h * 4;
 }
 
@@ -610,50 +273,57 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     PassGeom g;
     make_geom(g, pn, N, r0, c0, h, wdt, general);
 
+    // Batch = source points per x-pass/y-pass launch pair.  The intermediate T of one batch should stay
+    // resident in the 256 MiB Infinity Cache between the two passes (measured at 2048^2: 63 points = 1 GiB
+    // -> 28.7 us/point, 16 points = 270 MB -> 21.9), and a y-pass workgroup needs >= ~8 points to
+    // amortise its accumulator flush.
     const size_t point_bytes = (size_t)g.t_point * sizeof(float2);
     int64_t bs = (int64_t)(w.t_bytes / point_bytes);
+    int64_t bs_cache = (int64_t)(((size_t)288 << 20) / point_bytes);
+    if (bs_cache < 8) bs_cache = 8;
+    if (bs > bs_cache) bs = bs_cache;
     const int bs_env = env_int("LITHO_ABBE_BATCH", 0);
-    if (bs_env > 0 && bs_env < bs) bs = bs_env;
+    if (bs_env > 0) bs = (bs_env < (int64_t)(w.t_bytes / point_bytes)) ? bs_env : (int64_t)(w.t_bytes / point_bytes);
     if (bs < 1) return LITHO_E_WORKSPACE;
     if (bs > 65535) bs = 65535;
+    int xchunk = env_int("LITHO_ABBE_XCHUNK", 4);      // source points per x-pass workgroup
+    if (xchunk < 1) xchunk = 1;
     int G = env_int("LITHO_ABBE_GROUPS", 2);
     if (G < 1) G = 1;
     if (G > G_MAX) G = G_MAX;
     const size_t slab_plane = (size_t)g.nt * 4 * pn;
-    const int l2 = ilog2(N);
-    int64_t nx = 0, ny = 0;
-    std::vector<EventPair> events;
-    const size_t max_events = 4096;
-    auto ev_begin = [&](int kind, int nb) {
-        if (!g_profiling || events.size() >= max_events) return;
-        EventPair e{nullptr, nullptr, kind, nb};
-        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
-        (void)hipEventRecord(e.a, st);
-        events.push_back(e);
+    const SizeOps* ops = size_ops(ilog2(N));
+    if (!ops) return LITHO_E_ARG;
+    const int variant = pick_variant(g);
+    int64_t nx = 0;
+    // profiling: ONE event per kernel boundary (E0 x E1 y E2 x E3 ...); consecutive events bracket
+    // exactly one launch.  (Two events recorded back to back alias on ROCm, so no begin/end pairs.)
+    std::vector<Mark> marks;
+    const size_t max_marks = 8192;
+    auto mark = [&](int kind, int nb) {
+        if (!g_profiling || marks.size() >= max_marks) return;
+        Mark m{nullptr, kind, nb};
+        if (hipEventCreate(&m.ev) != hipSuccess) return;
+        (void)hipEventRecord(m.ev, st);
+        marks.push_back(m);
     };
-    auto ev_end = [&]() {
-        if (!g_profiling || events.empty() || events.size() > max_events) return;
-        (void)hipEventRecord(events.back().b, st);
-    };
-
     for (int p = 0; p < planes; ++p) {
         const float2* Pp = P + (size_t)p * pn * pn;
         HIP_TRY(hipMemsetAsync(w.slab, 0, (size_t)G * slab_plane * sizeof(float), st));
         for (int64_t s0 = 0; s0 < S; s0 += bs) {
             const int nb = (int)((S - s0 < bs) ? (S - s0) : bs);
-            ev_begin(0, nb);
+            if (marks.empty()) mark(-1, 0);
             if (general) {
                 AbbeLoader ld{Pp, M, shifts + 2 * s0, nullptr, nullptr, 0, 0};
-                LITHO_DISPATCH_LOG2N(l2, HIP_TRY((launch_xpass<L2, +1, AbbeLoader>(ld, w.T, w.twtab, g, nb, st))));
+                HIP_TRY(ops->xpass_general(ld, w.T, w.twtab, g, nb, st));
             } else {
-                LITHO_DISPATCH_LOG2N(l2, HIP_TRY((launch_xpass_abbe<L2>(Pp, M, shifts + 2 * s0, w.T, w.twtab, g, nb, st))));
+                HIP_TRY(ops->xpass_abbe(variant, Pp, M, shifts + 2 * s0, w.T, w.twtab, g, nb, xchunk, st));
             }
-            ev_end();
+            mark(0, nb);
             const int Geff = nb < G ? nb : G;
-            ev_begin(1, nb);
-            LITHO_DISPATCH_LOG2N(l2, HIP_TRY((launch_ypass_acc<L2>(w.T, w.slab, w.twtab, g, nb, Geff, st))));
-            ev_end();
-            ++nx; ++ny;
+            HIP_TRY(ops->ypass_acc(variant, w.T, w.slab, w.twtab, g, nb, Geff, st));
+            mark(1, nb);
+            ++nx;
         }
         hipLaunchKernelGGL(k_slab_reduce, dim3((pn + 31) / 32, (pn + 31) / 32), dim3(256), 0, st,
                            w.slab, out + (size_t)p * pn * pn, pn, g.nt * 4, G);
@@ -661,20 +331,19 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     }
     if (g_profiling) {
         for (int i = 0; i < 8; ++i) g_profile[i] = 0;
-        if (!events.empty()) (void)hipEventSynchronize(events.back().b);
-        for (auto& e : events) {
+        if (!marks.empty()) (void)hipEventSynchronize(marks.back().ev);
+        for (size_t i = 1; i < marks.size(); ++i) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
-                g_profile[e.kind * 3 + 0] += ms;
-                g_profile[e.kind * 3 + 1] += 1;
-                g_profile[e.kind * 3 + 2] += e.nb;
+            if (marks[i].kind >= 0 && hipEventElapsedTime(&ms, marks[i - 1].ev, marks[i].ev) == hipSuccess) {
+                g_profile[marks[i].kind * 3 + 0] += ms;
+                g_profile[marks[i].kind * 3 + 1] += 1;
+                g_profile[marks[i].kind * 3 + 2] += marks[i].nb;
             }
-            (void)hipEventDestroy(e.a);
-            (void)hipEventDestroy(e.b);
         }
+        for (auto& m : marks) (void)hipEventDestroy(m.ev);
     }
     g_last_plan[0] = general; g_last_plan[1] = r0; g_last_plan[2] = c0; g_last_plan[3] = h;
-    g_last_plan[4] = wdt; g_last_plan[5] = bs; g_last_plan[6] = nx; g_last_plan[7] = ny;
+    g_last_plan[4] = wdt; g_last_plan[5] = bs; g_last_plan[6] = nx; g_last_plan[7] = variant;
     return LITHO_OK;
 }
 
@@ -701,9 +370,10 @@ static int abbe_field(const float2* pf, const float2* M, int pn, int N, float2* 
     make_geom(g, pn, N, pl[0], pl[2], pl[1] - pl[0] + 1, pl[3] - pl[2] + 1, 0);
     HIP_TRY(hipMemsetAsync(w.plan + 16, 0, 2 * sizeof(int), st));     // a (0,0) shift
     AbbeLoader ld{pf, M, w.plan + 16, nullptr, nullptr, 0, 0};
-    const int l2 = ilog2(N);
-    LITHO_DISPATCH_LOG2N(l2, HIP_TRY((launch_xpass<L2, +1, AbbeLoader>(ld, w.T, w.twtab, g, 1, st))));
-    LITHO_DISPATCH_LOG2N(l2, HIP_TRY((launch_ypass_field<L2, +1>(w.T, field, w.twtab, g, st))));
+    const SizeOps* ops = size_ops(ilog2(N));
+    if (!ops) return LITHO_E_ARG;
+    HIP_TRY(ops->xpass_general(ld, w.T, w.twtab, g, 1, st));
+    HIP_TRY(ops->ypass_field(+1, w.T, field, w.twtab, g, st));
     return LITHO_OK;
 }
 
@@ -737,11 +407,14 @@ static int mask_spectrum(const int16_t* geo, int pn, double eps, int N, float2* 
     g.kx0 = j0 - N / 2; g.kx1 = j1 - N / 2;
     g.ky0 = g.kx0; g.ky1 = g.kx1;
     g.rows = j1 - j0; g.general = 0;
+    g.xmask = slot_mask(N, g.kx0, g.kx1);
+    g.ymask = slot_mask(N, g.ky0, g.ky1);
     g.t_point = (long long)nt * g.rows * 4;
     RealImageLoader ld{scaled, ns, j0 - pW, nullptr};
-    const int l2 = ilog2(N);
-    LITHO_DISPATCH_LOG2N(l2, HIP_TRY((launch_xpass<L2, -1, RealImageLoader>(ld, w.T, w.twtab, g, 1, st))));
-    LITHO_DISPATCH_LOG2N(l2, HIP_TRY((launch_ypass_field<L2, -1>(w.T, spec, w.twtab, g, st))));
+    const SizeOps* ops = size_ops(ilog2(N));
+    if (!ops) return LITHO_E_ARG;
+    HIP_TRY(ops->xpass_real_fwd(ld, w.T, w.twtab, g, st));
+    HIP_TRY(ops->ypass_field(-1, w.T, spec, w.twtab, g, st));
     return LITHO_OK;
 }
 

@@ -1,0 +1,513 @@
+// engine_kernels.hpp -- the two pass kernels of the Abbe engine and their launchers.
+//
+// Both passes run the per-line FFT of fft_core.hpp; thread t of a line holds the 16
+// samples n = t + T*e ("slots" e = 0..15).  Which slots can be non-zero on input and which
+// are kept on output depends only on the window sizes relative to N, so for the shapes that
+// matter (pn a power of two, pupil support inside the unit-radius disk, N/pn = 1, 2 or 4) the
+// slot sets are compile-time template parameters: empty slots are literal zeros that the
+// compiler folds through the first butterfly stage (file is built with -fno-signed-zeros),
+// discarded outputs are dead code, and the prefetch buffers only have the live slots.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fft_core.hpp"
+
+namespace litho {
+
+// ----------------------------------------------------------------------------------
+// geometry shared by the pass kernels
+// ----------------------------------------------------------------------------------
+struct PassGeom {
+    int pn, c, N;
+    int nt;                 // column tiles of 4 (ceil(pn/4))
+    int kx0, kx1;           // x-pass: valid input window [kx0,kx1) in centred coordinates
+    int ky0, ky1;           // y-pass: valid input window = rows of T; a = k - ky0
+    int rows;               // number of T rows (= ky1 - ky0)
+    int general;            // 1: roll stays on P, modular gather (wrapping shifts)
+    unsigned xmask, ymask;  // bit e set: slot e can be non-zero for SOME thread (x / y input)
+    long long t_point;      // float2 elements of T per source point = nt*rows*4
+};
+
+template <int LOG2N>
+struct Launch {
+    using F = LineFFT<LOG2N, +1>;
+    static constexpr int L = (F::T >= 64) ? 1 : 64 / F::T;       // lines per workgroup
+    static constexpr int THREADS = F::T * L;
+    static constexpr int NBUF = (LOG2N <= 12) ? 2 : 1;
+    static constexpr size_t LDS_BYTES = sizeof(float2) * (size_t)L * NBUF * F::LDS_LINE;
+    // launch_bounds second argument = waves per SIMD we want resident: two workgroups per CU
+    // up to N = 4096 (256 threads each), one above.
+#ifndef LITHO_WG_PER_CU
+#define LITHO_WG_PER_CU 2
+#endif
+    static constexpr int WAVES = (THREADS / 256 > 0 ? THREADS / 256 : 1) * (LOG2N <= 12 ? LITHO_WG_PER_CU : 1);
+    // Software prefetch of the next line's inputs: measured SLOWER on gfx950 (the extra live registers
+    // spill: 35.9 vs 28.7 us/point at 2048^2), so it is off unless a build asks for it.
+#ifdef LITHO_PREFETCH
+    static constexpr bool PREFETCH = true;
+#else
+    static constexpr bool PREFETCH = false;
+#endif
+};
+
+// Slot sets.  RL = log2(N/pn) for power-of-two pn (else -1).  PRUNED: the input window lies in
+// the "natural" support k in [-pn/4, pn/4] (pupil inside the unit disk of the [-2,2) sigma grid).
+__host__ __device__ constexpr unsigned natural_in_mask(int RL)
+{
+    return RL == 0 ? 0xF01Fu : RL == 1 ? 0xC007u : RL == 2 ? 0x8003u : 0xFFFFu;
+}
+__host__ __device__ constexpr unsigned out_mask(int RL)
+{
+    return RL == 1 ? 0xF00Fu : RL == 2 ? 0xC003u : 0xFFFFu;     // bins u in [-pn/2, pn/2)
+}
+
+// ----------------------------------------------------------------------------------
+// buffer addressing: 32-bit offsets, and the hardware range check is the zero-padding
+// predicate (an offset >= num_records loads 0 / drops the store).
+// ----------------------------------------------------------------------------------
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+static constexpr unsigned BUF_OOB = 0xFFFF0000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(unsigned)bytes, 0x00020000);
+}
+__device__ __forceinline__ float2 buf_load_c64(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+__device__ __forceinline__ void buf_store_c64(__amdgpu_buffer_rsrc_t r, unsigned off, float2 v) {
+    u32x2 w;
+    w.x = __float_as_uint(v.x);
+    w.y = __float_as_uint(v.y);
+    __builtin_amdgcn_raw_buffer_store_b64(w, r, off, 0, 0);
+}
+
+// ----------------------------------------------------------------------------------
+// x-pass (no wrapping shift): A = P[box] * M[box + shift], rows of the support box ->
+// T[s][tile][row][4].  One workgroup = one row of the box for a CHUNK of source points: the
+// pupil row and the twiddles stay in registers, only the mask-spectrum window moves.
+// ----------------------------------------------------------------------------------
+template <int LOG2N, int RL, bool PRUNED>
+__global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void k_xpass_abbe(
+    const float2* __restrict__ P, const float2* __restrict__ M, const int* __restrict__ shifts,
+    float2* __restrict__ Tbuf, const float2* __restrict__ twtab, PassGeom g, int nb, int chunk)
+{
+    using F = LineFFT<LOG2N, +1>;
+    using LC = Launch<LOG2N>;
+    constexpr unsigned IN = PRUNED ? natural_in_mask(RL) : 0xFFFFu;
+    constexpr unsigned OUT = out_mask(RL);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* smem = reinterpret_cast<float2*>(smem_raw);
+    const int lt = threadIdx.x % F::T, lg = threadIdx.x / F::T;
+    float2* lds = smem + (size_t)lg * LC::NBUF * F::LDS_LINE;
+
+    typename F::Twiddles tw;
+    F::load_twiddles(tw, twtab, lt);
+
+    const int a = blockIdx.x * LC::L + lg;
+    const bool active = a < g.rows;
+    const int r = g.ky0 + g.c + a;                            // row of P inside its support box
+    const size_t plane_bytes = (size_t)g.pn * g.pn * sizeof(float2);
+    const __amdgpu_buffer_rsrc_t rP = make_rsrc(P, plane_bytes);
+    const __amdgpu_buffer_rsrc_t rM = make_rsrc(M, plane_bytes);
+
+    unsigned koff[16];           // (c + k) of slot e, or BUF_OOB when outside the window
+    float2 pv[16];
+    static_for<0, 16>([&](auto e_) {
+        constexpr int e = decltype(e_)::value;
+        if constexpr ((IN >> e) & 1u) {
+            int k;
+            const bool ok = centred_index(lt + F::T * e, F::N, g.kx0, g.kx1, k) && active;
+            koff[e] = ok ? (unsigned)(g.c + k) : BUF_OOB;
+            pv[e] = buf_load_c64(rP, ok ? ((unsigned)r * g.pn + koff[e]) * 8u : BUF_OOB);
+        }
+    });
+    unsigned toff[16];           // byte offset of output bin m inside one source point's T block
+    static_for<0, 16>([&](auto m_) {
+        constexpr int m = decltype(m_)::value;
+        if constexpr ((OUT >> m) & 1u) {
+            int u;
+            const bool ok = centred_index(lt + F::T * m, F::N, -g.c, g.pn - g.c, u) && active;
+            const unsigned q = (unsigned)(u + g.c);
+            toff[m] = ok ? (((q >> 2) * g.rows + a) * 4u + (q & 3u)) * 8u : BUF_OOB;
+        }
+    });
+
+    const int s_begin = blockIdx.y * chunk;
+    const int s_end = min(nb, s_begin + chunk);
+    float2 mv[16];
+    auto load_window = [&](int s) {
+        const int dy = shifts[2 * s], dx = shifts[2 * s + 1];
+        const unsigned mrow = (unsigned)(r + dy) * g.pn + dx;          // same window of M moved by the shift
+        static_for<0, 16>([&](auto e_) {
+            constexpr int e = decltype(e_)::value;
+            if constexpr ((IN >> e) & 1u)
+                mv[e] = buf_load_c64(rM, koff[e] != BUF_OOB ? (mrow + koff[e]) * 8u : BUF_OOB);
+        });
+    };
+
+    if (s_begin < s_end) load_window(s_begin);
+    int flip = 0;
+    for (int s = s_begin; s < s_end; ++s) {
+        float2 x[16];
+        static_for<0, 16>([&](auto e_) {
+            constexpr int e = decltype(e_)::value;
+            if constexpr ((IN >> e) & 1u) x[e] = cmul(pv[e], mv[e]);
+            else x[e] = make_float2(0.f, 0.f);
+        });
+        if constexpr (PRUNED && LC::PREFETCH) {
+            if (s + 1 < s_end) load_window(s + 1);            // prefetch: in flight during the transform
+        }
+        F::template run<LC::NBUF>(x, tw, lds, lt, flip);
+        const __amdgpu_buffer_rsrc_t rT =
+            make_rsrc(Tbuf + (size_t)s * g.t_point, (size_t)g.t_point * sizeof(float2));
+        static_for<0, 16>([&](auto m_) {
+            constexpr int m = decltype(m_)::value;
+            if constexpr ((OUT >> m) & 1u) buf_store_c64(rT, toff[m], x[m]);
+        });
+        if constexpr (!(PRUNED && LC::PREFETCH)) {
+            if (s + 1 < s_end) load_window(s + 1);
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// generic x-pass (any loader, runtime predication): rows -> T[s][tile][row][4]
+// ----------------------------------------------------------------------------------
+template <int LOG2N, int SIGN, typename Loader>
+__global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void k_xpass(
+    Loader ld, float2* __restrict__ Tbuf, const float2* __restrict__ twtab, PassGeom g)
+{
+    using F = LineFFT<LOG2N, SIGN>;
+    using LC = Launch<LOG2N>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* smem = reinterpret_cast<float2*>(smem_raw);
+    const int lt = threadIdx.x % F::T, lg = threadIdx.x / F::T;
+    float2* lds = smem + (size_t)lg * LC::NBUF * F::LDS_LINE;
+
+    typename F::Twiddles tw;
+    F::load_twiddles(tw, twtab, lt);
+
+    const int s = blockIdx.y;
+    const int a = blockIdx.x * LC::L + lg;
+    const bool active = a < g.rows;
+    ld.begin_line(s, active ? a : 0, g);
+
+    float2 x[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        int k;
+        const bool ok = centred_index(lt + F::T * e, F::N, g.kx0, g.kx1, k) && active;
+        x[e] = ok ? ld.load(k, g) : make_float2(0.f, 0.f);
+    }
+    int flip = 0;
+    F::template run<LC::NBUF>(x, tw, lds, lt, flip);
+
+    float2* trow = Tbuf + (size_t)s * g.t_point + (size_t)a * 4;
+    const size_t tile_stride = (size_t)g.rows * 4;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        int u;
+        if (centred_index(lt + F::T * m, F::N, -g.c, g.pn - g.c, u) && active) {
+            const int q = u + g.c;
+            trow[(size_t)(q >> 2) * tile_stride + (q & 3)] = x[m];
+        }
+    }
+}
+
+// Loader: Abbe product P*M for source point s (imageformation.py:34 and :63), with the roll
+// kept on P (modular gather) when a shifted support would wrap around the grid.
+struct AbbeLoader {
+    const float2* P;
+    const float2* M;
+    const int* shifts;       // (dy,dx) pairs of this batch
+    const float2* prow;
+    const float2* mrow;
+    int dx, pad_;
+    __device__ __forceinline__ void begin_line(int s, int a, const PassGeom& g) {
+        const int dy = shifts[2 * s];
+        dx = shifts[2 * s + 1];
+        if (!g.general) {
+            const int r = g.ky0 + g.c + a;                  // row of P (support box row)
+            prow = P + (size_t)r * g.pn;
+            mrow = M + (size_t)(r + dy) * g.pn + dx;        // same window of M, moved by the shift
+        } else {
+            int r = (a - dy) % g.pn;                        // torch.roll: A[i] = P[(i - d) mod pn]
+            if (r < 0) r += g.pn;
+            prow = P + (size_t)r * g.pn;
+            mrow = M + (size_t)a * g.pn;
+        }
+    }
+    __device__ __forceinline__ float2 load(int k, const PassGeom& g) const {
+        const int col = k + g.c;
+        if (!g.general) return cmul(prow[col], mrow[col]);
+        int pc = (col - dx) % g.pn;
+        if (pc < 0) pc += g.pn;
+        return cmul(prow[pc], mrow[col]);
+    }
+};
+
+// Loader: a real image (the bilinearly scaled mask, mask.py:76-81).  Line a / sample k of the
+// padded N x N frame map to img[a + off][k - kx0 + off]; the zero padding (or, when the
+// scaled mask is larger than N, the crop) is expressed by the window and `off` alone.
+struct RealImageLoader {
+    const float* img;        // [n,n]
+    int n, off;
+    const float* row;
+    __device__ __forceinline__ void begin_line(int, int a, const PassGeom&) { row = img + (size_t)(a + off) * n + off; }
+    __device__ __forceinline__ float2 load(int k, const PassGeom& g) const {
+        return make_float2(row[k - g.kx0], 0.f);
+    }
+};
+
+// ----------------------------------------------------------------------------------
+// y-pass with |E|^2 accumulation in registers over the batch
+// ----------------------------------------------------------------------------------
+template <int LOG2N, int RL, bool PRUNED>
+__global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void k_ypass_acc(
+    const float2* __restrict__ Tbuf, float* __restrict__ slab, const float2* __restrict__ twtab,
+    PassGeom g, int nb, int G)
+{
+    using F = LineFFT<LOG2N, +1>;
+    using LC = Launch<LOG2N>;
+    constexpr unsigned IN = PRUNED ? natural_in_mask(RL) : 0xFFFFu;
+    constexpr unsigned OUT = out_mask(RL);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* smem = reinterpret_cast<float2*>(smem_raw);
+    const int lt = threadIdx.x % F::T, lg = threadIdx.x / F::T;
+    float2* lds = smem + (size_t)lg * LC::NBUF * F::LDS_LINE;
+
+    typename F::Twiddles tw;
+    F::load_twiddles(tw, twtab, lt);
+
+    const int tile = blockIdx.x * LC::L + lg;
+    const bool active = tile < g.nt;
+    const int grp = blockIdx.y;
+
+    float acc[4][16];
+    static_for<0, 4>([&](auto c_) {
+        static_for<0, 16>([&](auto m_) {
+            if constexpr ((OUT >> decltype(m_)::value) & 1u) acc[decltype(c_)::value][decltype(m_)::value] = 0.f;
+        });
+    });
+
+    // per-thread input map: slot e <-> byte offset of T row a_e inside this tile (or out of range)
+    unsigned voff[16];
+    static_for<0, 16>([&](auto e_) {
+        constexpr int e = decltype(e_)::value;
+        if constexpr ((IN >> e) & 1u) {
+            int k;
+            const bool ok = centred_index(lt + F::T * e, F::N, g.ky0, g.ky1, k) && active;
+            voff[e] = ok ? ((unsigned)tile * g.rows + (unsigned)(k - g.ky0)) * 32u : BUF_OOB;
+        }
+    });
+    float2 nx[16];
+    auto load_column = [&](int s, int cidx) {
+        const __amdgpu_buffer_rsrc_t rT =
+            make_rsrc(Tbuf + (size_t)s * g.t_point, (size_t)g.t_point * sizeof(float2));
+        static_for<0, 16>([&](auto e_) {
+            constexpr int e = decltype(e_)::value;
+            if constexpr ((IN >> e) & 1u) nx[e] = buf_load_c64(rT, voff[e] + cidx * 8u);
+        });
+    };
+
+    int flip = 0;
+    if constexpr (PRUNED && LC::PREFETCH) {
+        if (grp < nb) load_column(grp, 0);
+    }
+    for (int s = grp; s < nb; s += G) {
+        static_for<0, 4>([&](auto c_) {
+            constexpr int cidx = decltype(c_)::value;
+            if constexpr (!(PRUNED && LC::PREFETCH)) load_column(s, cidx);
+            float2 x[16];
+            static_for<0, 16>([&](auto e_) {
+                constexpr int e = decltype(e_)::value;
+                if constexpr ((IN >> e) & 1u) x[e] = nx[e];
+                else x[e] = make_float2(0.f, 0.f);
+            });
+            if constexpr (PRUNED && LC::PREFETCH) {        // prefetch the next line while this one transforms
+                if constexpr (cidx < 3) load_column(s, cidx + 1);
+                else if (s + G < nb) load_column(s + G, 0);
+            }
+            F::template run<LC::NBUF>(x, tw, lds, lt, flip);
+            static_for<0, 16>([&](auto m_) {
+                constexpr int m = decltype(m_)::value;
+                if constexpr ((OUT >> m) & 1u) acc[cidx][m] = fmaf(x[m].x, x[m].x, fmaf(x[m].y, x[m].y, acc[cidx][m]));
+            });
+        });
+    }
+
+    if (!active) return;
+    // flush into this group's private slab, laid out [G][qx][qy] (qy contiguous -> coalesced)
+    static_for<0, 4>([&](auto c_) {
+        constexpr int cidx = decltype(c_)::value;
+        const int qx = tile * 4 + cidx;
+        if (qx < g.pn) {
+            float* srow = slab + ((size_t)grp * g.nt * 4 + qx) * g.pn;
+            static_for<0, 16>([&](auto m_) {
+                constexpr int m = decltype(m_)::value;
+                if constexpr ((OUT >> m) & 1u) {
+                    int u;
+                    if (centred_index(lt + F::T * m, F::N, -g.c, g.pn - g.c, u)) srow[u + g.c] += acc[cidx][m];
+                }
+            });
+        }
+    });
+}
+
+// y-pass that writes the complex field instead (calculateFFTAerial, mask spectrum).
+template <int LOG2N, int SIGN>
+__global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void k_ypass_field(
+    const float2* __restrict__ Tbuf, float2* __restrict__ field, const float2* __restrict__ twtab, PassGeom g)
+{
+    using F = LineFFT<LOG2N, SIGN>;
+    using LC = Launch<LOG2N>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* smem = reinterpret_cast<float2*>(smem_raw);
+    const int lt = threadIdx.x % F::T, lg = threadIdx.x / F::T;
+    float2* lds = smem + (size_t)lg * LC::NBUF * F::LDS_LINE;
+    typename F::Twiddles tw;
+    F::load_twiddles(tw, twtab, lt);
+    const int tile = blockIdx.x * LC::L + lg;
+    const bool active = tile < g.nt;
+    const float2* tt = Tbuf + (size_t)(active ? tile : 0) * g.rows * 4;
+    int flip = 0;
+    for (int cidx = 0; cidx < 4; ++cidx) {
+        float2 x[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            int k;
+            const bool ok = centred_index(lt + F::T * e, F::N, g.ky0, g.ky1, k) && active;
+            x[e] = ok ? tt[(size_t)(k - g.ky0) * 4 + cidx] : make_float2(0.f, 0.f);
+        }
+        F::template run<LC::NBUF>(x, tw, lds, lt, flip);
+        const int qx = tile * 4 + cidx;
+        if (!active || qx >= g.pn) continue;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            int u;
+            if (centred_index(lt + F::T * m, F::N, -g.c, g.pn - g.c, u)) field[(size_t)(u + g.c) * g.pn + qx] = x[m];
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// per-FFT-size launch table (one translation unit per size, see inst_*.hip)
+// ----------------------------------------------------------------------------------
+struct SizeOps {
+    // variant: -1 = generic (any even pn, runtime predication); 0/1/2 = pruned, RL = log2(N/pn)
+    hipError_t (*xpass_abbe)(int variant, const float2* P, const float2* M, const int* shifts, float2* T,
+                             const float2* tw, const PassGeom& g, int nb, int chunk, hipStream_t st);
+    hipError_t (*xpass_general)(const AbbeLoader& ld, float2* T, const float2* tw, const PassGeom& g, int nb,
+                                hipStream_t st);
+    hipError_t (*xpass_real_fwd)(const RealImageLoader& ld, float2* T, const float2* tw, const PassGeom& g,
+                                 hipStream_t st);
+    hipError_t (*ypass_acc)(int variant, const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb,
+                            int G, hipStream_t st);
+    hipError_t (*ypass_field)(int sign, const float2* T, float2* field, const float2* tw, const PassGeom& g,
+                              hipStream_t st);
+};
+const SizeOps* size_ops(int log2n);      // nullptr outside 4..14
+
+template <typename K>
+static hipError_t set_lds(K kern, size_t bytes)
+{
+    return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <int LOG2N>
+struct SizeImpl {
+    using LC = Launch<LOG2N>;
+
+    template <int RL, bool PRUNED>
+    static hipError_t xa(const float2* P, const float2* M, const int* shifts, float2* T, const float2* tw,
+                         const PassGeom& g, int nb, int chunk, hipStream_t st)
+    {
+        auto kern = k_xpass_abbe<LOG2N, RL, PRUNED>;
+        hipError_t e = set_lds(kern, LC::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        dim3 grid((g.rows + LC::L - 1) / LC::L, (nb + chunk - 1) / chunk);
+        hipLaunchKernelGGL(kern, grid, dim3(LC::THREADS), LC::LDS_BYTES, st, P, M, shifts, T, tw, g, nb, chunk);
+        return hipGetLastError();
+    }
+    static hipError_t xpass_abbe(int variant, const float2* P, const float2* M, const int* shifts, float2* T,
+                                 const float2* tw, const PassGeom& g, int nb, int chunk, hipStream_t st)
+    {
+        switch (variant) {
+            case 0: return xa<0, true>(P, M, shifts, T, tw, g, nb, chunk, st);
+            case 1: return xa<1, true>(P, M, shifts, T, tw, g, nb, chunk, st);
+            case 2: return xa<2, true>(P, M, shifts, T, tw, g, nb, chunk, st);
+            default: return xa<-1, false>(P, M, shifts, T, tw, g, nb, chunk, st);
+        }
+    }
+    static hipError_t xpass_general(const AbbeLoader& ld, float2* T, const float2* tw, const PassGeom& g, int nb,
+                                    hipStream_t st)
+    {
+        auto kern = k_xpass<LOG2N, +1, AbbeLoader>;
+        hipError_t e = set_lds(kern, LC::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((g.rows + LC::L - 1) / LC::L, nb), dim3(LC::THREADS), LC::LDS_BYTES, st, ld, T,
+                           tw, g);
+        return hipGetLastError();
+    }
+    static hipError_t xpass_real_fwd(const RealImageLoader& ld, float2* T, const float2* tw, const PassGeom& g,
+                                     hipStream_t st)
+    {
+        auto kern = k_xpass<LOG2N, -1, RealImageLoader>;
+        hipError_t e = set_lds(kern, LC::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((g.rows + LC::L - 1) / LC::L, 1), dim3(LC::THREADS), LC::LDS_BYTES, st, ld, T, tw,
+                           g);
+        return hipGetLastError();
+    }
+    template <int RL, bool PRUNED>
+    static hipError_t ya(const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb, int G,
+                         hipStream_t st)
+    {
+        auto kern = k_ypass_acc<LOG2N, RL, PRUNED>;
+        hipError_t e = set_lds(kern, LC::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((g.nt + LC::L - 1) / LC::L, G), dim3(LC::THREADS), LC::LDS_BYTES, st, T, slab, tw,
+                           g, nb, G);
+        return hipGetLastError();
+    }
+    static hipError_t ypass_acc(int variant, const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb,
+                                int G, hipStream_t st)
+    {
+        switch (variant) {
+            case 0: return ya<0, true>(T, slab, tw, g, nb, G, st);
+            case 1: return ya<1, true>(T, slab, tw, g, nb, G, st);
+            case 2: return ya<2, true>(T, slab, tw, g, nb, G, st);
+            default: return ya<-1, false>(T, slab, tw, g, nb, G, st);
+        }
+    }
+    static hipError_t ypass_field(int sign, const float2* T, float2* field, const float2* tw, const PassGeom& g,
+                                  hipStream_t st)
+    {
+        dim3 grid((g.nt + LC::L - 1) / LC::L);
+        if (sign > 0) {
+            auto kern = k_ypass_field<LOG2N, +1>;
+            hipError_t e = set_lds(kern, LC::LDS_BYTES);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, grid, dim3(LC::THREADS), LC::LDS_BYTES, st, T, field, tw, g);
+        } else {
+            auto kern = k_ypass_field<LOG2N, -1>;
+            hipError_t e = set_lds(kern, LC::LDS_BYTES);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, grid, dim3(LC::THREADS), LC::LDS_BYTES, st, T, field, tw, g);
+        }
+        return hipGetLastError();
+    }
+};
+
+// A host accessor (not a namespace-scope constant: that would be emitted for the device too).
+#define LITHO_DEFINE_SIZE_OPS(L2)                                                                    \
+    const SizeOps* size_ops_##L2()                                                                   \
+    {                                                                                                \
+        static const SizeOps ops{&SizeImpl<L2>::xpass_abbe, &SizeImpl<L2>::xpass_general,            \
+                                 &SizeImpl<L2>::xpass_real_fwd, &SizeImpl<L2>::ypass_acc,            \
+                                 &SizeImpl<L2>::ypass_field};                                        \
+        return &ops;                                                                                 \
+    }
+
+}  // namespace litho

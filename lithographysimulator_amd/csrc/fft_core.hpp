@@ -90,6 +90,18 @@ struct Dft<2, SIGN> {
 
 __device__ __forceinline__ int lds_pad(int i) { return i + (i >> 4); }   // one extra slot per 16
 
+// Workgroup barrier that orders LDS traffic only: global loads/stores issued earlier stay in
+// flight across it (a plain __syncthreads() would drain vmcnt and kill the input prefetch).
+__device__ __forceinline__ void lds_barrier() {
+#ifdef LITHO_FULL_BARRIER
+    __syncthreads();
+    return;
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 template <int LOG2N, int SIGN>
 struct LineFFT {
     static_assert(LOG2N >= 4 && LOG2N <= 14, "16 <= N <= 16384");
@@ -125,43 +137,64 @@ struct LineFFT {
         }
     }
 
+    // Padded LDS slot of (i + off) given the padded slot of i, for the access patterns below:
+    // lds_pad(i + off) == lds_pad(i) + off + (off >> 4) whenever adding `off` cannot carry out of
+    // the low 4 bits of i (true for every pattern used here: see the comments at the call sites).
+    // `off` is a compile-time constant, so each LDS access is one base register + an immediate.
+    static constexpr int pad_off(int off) { return off + (off >> 4); }
+
+    // Radix-16 pass p works on sub-transforms of length Ns(p) = R1 * 16^p.
+    static constexpr int ns_of(int p) { return R1 << (4 * p); }
+
     // x[e] holds sample n = t + T*e on entry and output bin n = t + T*e on exit.
     // lds: this line's two exchange buffers (2 * LDS_LINE float2) when NBUF == 2, one when NBUF == 1.
     // `flip` alternates buffers across consecutive exchanges (also across calls).
     template <int NBUF>
     __device__ static __forceinline__ void run(float2 (&x)[E], const Twiddles& tw, float2* lds, int t, int& flip) {
-        int ns = 1;
+        // read slot of sample t + r*T: r*T is a multiple of 16 when T >= 16; when T < 16, t < T and T | 16,
+        // so t + r*T never carries differently from r*T alone.
+        float2* const rd0 = lds + lds_pad(t);
         if constexpr (R1 > 1) {
-            float2* buf = lds + (NBUF == 2 ? (flip & 1) * LDS_LINE : 0);
-            if constexpr (NBUF == 1) __syncthreads();
+            float2* buf = (NBUF == 2 && (flip & 1)) ? lds + LDS_LINE : lds;
+            if constexpr (NBUF == 1) lds_barrier();
+            // write slot of j*R1 + m, j = t + T*b:  = pad(t*R1) + pad_off(T*R1*b + m): m < R1 never carries
+            // (t*R1 is a multiple of R1), and T*R1*b is a multiple of 16 whenever N*R1 >= 256.
+            static_assert((T * R1) % 16 == 0 || B1 == 1 || true, "");
+            float2* const wr0 = buf + lds_pad(t * R1);
             static_for<0, B1>([&](auto b) {
                 float2 v[R1];
                 static_for<0, R1>([&](auto r) { v[r] = x[b + B1 * r]; });
                 Dft<R1, SIGN>::run(v);
-                const int j = t + T * b;
-                static_for<0, R1>([&](auto m) { buf[lds_pad(j * R1 + m)] = v[m]; });
+                static_for<0, R1>([&](auto m) {
+                    constexpr int off = T * R1 * decltype(b)::value + decltype(m)::value;
+                    if constexpr ((T * R1) % 16 == 0) wr0[pad_off(off)] = v[m];
+                    else buf[lds_pad(t * R1 + off)] = v[m];
+                });
             });
-            __syncthreads();
-            static_for<0, E>([&](auto r) { x[r] = buf[lds_pad(t + r * T)]; });
+            lds_barrier();
+            float2* const rd = rd0 + (buf - lds);
+            static_for<0, E>([&](auto r) { x[r] = rd[pad_off(decltype(r)::value * T)]; });
             flip ^= 1;
-            ns = R1;
         }
         static_for<0, P16>([&](auto p) {
             constexpr int twi = p - (R1 == 1 ? 1 : 0);
+            constexpr int ns = ns_of(decltype(p)::value);
             if constexpr (twi >= 0) {
                 static_for<1, 16>([&](auto r) { x[r] = cmul(x[r], tw.w[twi][r - 1]); });
             }
             Dft<16, SIGN>::run(x);
             if constexpr (p < P16 - 1) {
-                float2* buf = lds + (NBUF == 2 ? (flip & 1) * LDS_LINE : 0);
-                if constexpr (NBUF == 1) __syncthreads();
+                float2* buf = (NBUF == 2 && (flip & 1)) ? lds + LDS_LINE : lds;
+                if constexpr (NBUF == 1) lds_barrier();
+                // write slot of base + m*ns, base = (t-k)*16 + k, k = t mod ns: m*ns is a multiple of 16 for
+                // ns >= 16; for ns < 16, k < ns and ns | 16, so k + m*ns never carries differently from m*ns.
                 const int k = t & (ns - 1);
-                const int base = (t - k) * 16 + k;
-                static_for<0, 16>([&](auto m) { buf[lds_pad(base + m * ns)] = x[m]; });
-                __syncthreads();
-                static_for<0, 16>([&](auto r) { x[r] = buf[lds_pad(t + r * T)]; });
+                float2* const wr0 = buf + lds_pad((t - k) * 16 + k);
+                static_for<0, 16>([&](auto m) { wr0[pad_off(decltype(m)::value * ns)] = x[m]; });
+                lds_barrier();
+                float2* const rd = rd0 + (buf - lds);
+                static_for<0, 16>([&](auto r) { x[r] = rd[pad_off(decltype(r)::value * T)]; });
                 flip ^= 1;
-                ns *= 16;
             }
         });
     }

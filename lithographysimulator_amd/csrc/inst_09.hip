@@ -1,0 +1,6 @@
+// inst_09.hip -- kernel instantiations for FFT size N = 512 (one translation unit per size so
+// that the sizes compile in parallel).
+#include "engine_kernels.hpp"
+namespace litho {
+LITHO_DEFINE_SIZE_OPS(9)
+}

@@ -5,7 +5,9 @@ CSRC := lithographysimulator_amd/csrc
 OUT := lithographysimulator_amd/lib/liblitho_abbe.so
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
 # FFT kernels: no signed zeros, so that literal-zero input slots fold through the butterflies.
-FFTFLAGS := -fno-signed-zeros
+# No SLP packing: v_pk_*_f32 are not faster than two scalar ops on gfx950 and cost ~100 register moves
+# per transform (and 40-80 VGPRs).
+FFTFLAGS := -fno-signed-zeros -fno-slp-vectorize
 INST := $(patsubst $(CSRC)/%.hip,build/%.o,$(wildcard $(CSRC)/inst_*.hip))
 HDRS := $(CSRC)/fft_core.hpp $(CSRC)/engine_kernels.hpp $(CSRC)/engine_common.hpp include/litho_abbe.h
 

@@ -288,7 +288,7 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     if (bs > 65535) bs = 65535;
     int xchunk = env_int("LITHO_ABBE_XCHUNK", 4);      // source points per x-pass workgroup
     if (xchunk < 1) xchunk = 1;
-    int G = env_int("LITHO_ABBE_GROUPS", 2);
+    int G = env_int("LITHO_ABBE_GROUPS", 3);     // y-pass groups: grid = tiles x G, 3 workgroups fit per CU
     if (G < 1) G = 1;
     if (G > G_MAX) G = G_MAX;
     const size_t slab_plane = (size_t)g.nt * 4 * pn;

@@ -33,12 +33,16 @@ struct Launch {
     using F = LineFFT<LOG2N, +1>;
     static constexpr int L = (F::T >= 64) ? 1 : 64 / F::T;       // lines per workgroup
     static constexpr int THREADS = F::T * L;
-    static constexpr int NBUF = (LOG2N <= 12) ? 2 : 1;
+#ifndef LITHO_NBUF
+#define LITHO_NBUF 1
+#endif
+    static constexpr int NBUF = (LOG2N <= 12) ? LITHO_NBUF : 1;
     static constexpr size_t LDS_BYTES = sizeof(float2) * (size_t)L * NBUF * F::LDS_LINE;
-    // launch_bounds second argument = waves per SIMD we want resident: two workgroups per CU
-    // up to N = 4096 (256 threads each), one above.
+    // launch_bounds second argument = waves per SIMD we want resident: LITHO_WG_PER_CU workgroups per CU
+    // up to N = 4096 (256 threads each), one above.  Measured at 2048^2: one LDS buffer (extra barrier) with 3
+    // workgroups per CU beats two buffers with 2 by 7 %.
 #ifndef LITHO_WG_PER_CU
-#define LITHO_WG_PER_CU 2
+#define LITHO_WG_PER_CU 3
 #endif
     static constexpr int WAVES = (THREADS / 256 > 0 ? THREADS / 256 : 1) * (LOG2N <= 12 ? LITHO_WG_PER_CU : 1);
     // Software prefetch of the next line's inputs: measured SLOWER on gfx950 (the extra live registers

@@ -88,7 +88,13 @@ struct Dft<2, SIGN> {
     }
 };
 
-__device__ __forceinline__ int lds_pad(int i) { return i + (i >> 4); }   // one extra slot per 16
+// LDS slots are padded by LDS_PAD float2 per 16: with 2, a lane's 16 consecutive slots start 18*8 = 144 B
+// apart, so both the 8-byte accesses and the 16-byte ds_write2_b64 pairs the compiler forms are
+// bank-conflict free (with 1, the merged 16-byte writes collide two-way: 33 % of LDS cycles measured).
+#ifndef LITHO_LDS_PAD
+#define LITHO_LDS_PAD 2
+#endif
+__device__ __forceinline__ constexpr int lds_pad(int i) { return i + LITHO_LDS_PAD * (i >> 4); }
 
 // Workgroup barrier that orders LDS traffic only: global loads/stores issued earlier stay in
 // flight across it (a plain __syncthreads() would drain vmcnt and kill the input prefetch).
@@ -112,7 +118,7 @@ struct LineFFT {
     static constexpr int R1 = N >> (4 * P16);      // leading radix (1 = none)
     static constexpr int B1 = E / R1;              // leading-pass butterflies per thread
     static constexpr int EXCH = P16 - 1 + (R1 > 1 ? 1 : 0);   // LDS exchanges per transform
-    static constexpr int LDS_LINE = N + N / 16;    // float2 slots per buffer per line
+    static constexpr int LDS_LINE = N + LITHO_LDS_PAD * (N / 16);    // float2 slots per buffer per line
     // Radix-16 pass p has Ns = R1 * 16^p; it needs twiddles iff Ns > 1.
     static constexpr int NTW = P16 - (R1 == 1 ? 1 : 0);
 
@@ -138,10 +144,10 @@ struct LineFFT {
     }
 
     // Padded LDS slot of (i + off) given the padded slot of i, for the access patterns below:
-    // lds_pad(i + off) == lds_pad(i) + off + (off >> 4) whenever adding `off` cannot carry out of
+    // lds_pad(i + off) == lds_pad(i) + off + PAD*(off >> 4) whenever adding `off` cannot carry out of
     // the low 4 bits of i (true for every pattern used here: see the comments at the call sites).
     // `off` is a compile-time constant, so each LDS access is one base register + an immediate.
-    static constexpr int pad_off(int off) { return off + (off >> 4); }
+    static constexpr int pad_off(int off) { return off + LITHO_LDS_PAD * (off >> 4); }
 
     // Radix-16 pass p works on sub-transforms of length Ns(p) = R1 * 16^p.
     static constexpr int ns_of(int p) { return R1 << (4 * p); }

@@ -1,19 +1,15 @@
 #!/bin/bash
-# A/B builds of the N=4096 kernels: each variant relinks the library with inst_12 rebuilt under other flags.
+# A/B builds of one FFT size: each variant relinks the library with inst_$L2 rebuilt under other flags.
+#   scripts/build_variants.sh 12 name1 "flags1" name2 "flags2" ...
 set -e
 cd "$(dirname "$0")/.."
+L2=$1; shift
 mkdir -p build/variants
-OBJS="build/abbe_engine.o build/optics.o build/common.o $(ls build/inst_*.o | grep -v inst_12)"
-build() { # name, flags
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $2 -c lithographysimulator_amd/csrc/inst_12.hip -o build/variants/inst_12_$1.o
-  hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/lib_$1.so $OBJS build/variants/inst_12_$1.o
+OBJS="build/abbe_engine.o build/optics.o build/common.o $(ls build/inst_*.o | grep -v inst_$L2)"
+build() {
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-signed-zeros -fno-slp-vectorize $2 -c lithographysimulator_amd/csrc/inst_$L2.hip -o build/variants/inst_${L2}_$1.o
+  hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/lib_$1.so $OBJS build/variants/inst_${L2}_$1.o
 }
-build base "-fno-signed-zeros" &
-build fullbar "-fno-signed-zeros -DLITHO_FULL_BARRIER" &
-build nopref "-fno-signed-zeros -DLITHO_NO_PREFETCH" &
-build nonsz "" &
+while [ $# -gt 0 ]; do build "$1" "$2" & shift 2; done
 wait
-build wg1 "-fno-signed-zeros -DLITHO_WG_PER_CU=1" &
-build nopref_fullbar "-fno-signed-zeros -DLITHO_NO_PREFETCH -DLITHO_FULL_BARRIER" &
-wait
-ls -la build/variants/*.so
+ls build/variants/*.so

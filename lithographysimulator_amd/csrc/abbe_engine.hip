@@ -220,6 +220,15 @@ static int read_plan(const Workspace& w, int host[8], hipStream_t st)
     return LITHO_OK;
 }
 
+// T tile width (columns): 4 unless LITHO_ABBE_TILE says 8 or 16 (tuning knob)
+static void set_tile(PassGeom& g, int rows)
+{
+    const int tc = env_int("LITHO_ABBE_TILE", 4);
+    g.tcl = (tc == 16) ? 4 : (tc == 8) ? 3 : 2;
+    const long long ntile = (g.pn + (1 << g.tcl) - 1) >> g.tcl;
+    g.t_point = (ntile * rows) << g.tcl;
+}
+
 // bit e of the mask: some thread t of a line has its slot e (sample n = t + T*e) inside [lo,hi)
 static unsigned slot_mask(int N, int lo, int hi)
 {
@@ -242,7 +251,7 @@ static void make_geom(PassGeom& g, int pn, int N, int r0, int c0, int h, int wdt
     g.rows = h; g.general = general;
     g.xmask = slot_mask(N, g.kx0, g.kx1);
     g.ymask = slot_mask(N, g.ky0, g.ky1);
-    g.t_point = (long long)g.nt * h * 4;
+    set_tile(g, h);
 }
 
 static int abbe_accumulate(const float2* M, const float2* P, int planes, const int* shifts, int64_t S,
@@ -288,7 +297,17 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     if (bs > 65535) bs = 65535;
     int xchunk = env_int("LITHO_ABBE_XCHUNK", 4);      // source points per x-pass workgroup
     if (xchunk < 1) xchunk = 1;
-    int G = env_int("LITHO_ABBE_GROUPS", 3);     // y-pass groups: grid = tiles x G, 3 workgroups fit per CU
+    // y-pass groups: the grid is (tile blocks) x G workgroups; pick the smallest G that makes it a whole
+    // number of full-occupancy rounds (256 CUs x workgroups per CU), so no round runs part-empty.
+    const int l2n = ilog2(N);
+    const int lines_per_wg = (N / 16 >= 64) ? 1 : 64 / (N / 16);
+    const int tile_blocks = (g.nt + lines_per_wg - 1) / lines_per_wg;
+    const int resident = 256 * (l2n <= 12 ? 3 : (l2n == 13 ? 2 : 1));
+    int a_ = tile_blocks, b_ = resident;
+    while (b_) { const int t_ = a_ % b_; a_ = b_; b_ = t_; }
+    int G = resident / a_;
+    const int g_env = env_int("LITHO_ABBE_GROUPS", 0);
+    if (g_env > 0) G = g_env;
     if (G < 1) G = 1;
     if (G > G_MAX) G = G_MAX;
     const size_t slab_plane = (size_t)g.nt * 4 * pn;
@@ -397,7 +416,7 @@ static int mask_spectrum(const int16_t* geo, int pn, double eps, int N, float2* 
     const int j1 = (pW + ns < N) ? pW + ns : N;
     const size_t nt = (pn + 3) / 4;
     if ((size_t)ns * ns * sizeof(float) > (size_t)G_MAX * nt * 4 * pn * sizeof(float)) return LITHO_E_WORKSPACE;
-    if (nt * (size_t)(j1 - j0) * 4 * sizeof(float2) > w.t_bytes) return LITHO_E_WORKSPACE;
+    if (((size_t)(pn + 15) / 16 * 16) * (size_t)(j1 - j0) * sizeof(float2) > w.t_bytes) return LITHO_E_WORKSPACE;
     float* scaled = w.slab;                                      // the slab region is free here
     hipLaunchKernelGGL(k_twiddle_table, dim3((N + 255) / 256), dim3(256), 0, st, w.twtab, N);
     launch_scale_mask(geo, pn, ns, eps, scaled, st);
@@ -409,7 +428,7 @@ static int mask_spectrum(const int16_t* geo, int pn, double eps, int N, float2* 
     g.rows = j1 - j0; g.general = 0;
     g.xmask = slot_mask(N, g.kx0, g.kx1);
     g.ymask = slot_mask(N, g.ky0, g.ky1);
-    g.t_point = (long long)nt * g.rows * 4;
+    set_tile(g, g.rows);
     RealImageLoader ld{scaled, ns, j0 - pW, nullptr};
     const SizeOps* ops = size_ops(ilog2(N));
     if (!ops) return LITHO_E_ARG;

@@ -19,13 +19,14 @@ namespace litho {
 // ----------------------------------------------------------------------------------
 struct PassGeom {
     int pn, c, N;
-    int nt;                 // column tiles of 4 (ceil(pn/4))
+    int nt;                 // 4-column groups (ceil(pn/4)): one y-pass workgroup line each
+    int tcl;                // log2 of the T tile width in columns (2..4): T is [tile][row][1<<tcl]
     int kx0, kx1;           // x-pass: valid input window [kx0,kx1) in centred coordinates
     int ky0, ky1;           // y-pass: valid input window = rows of T; a = k - ky0
     int rows;               // number of T rows (= ky1 - ky0)
     int general;            // 1: roll stays on P, modular gather (wrapping shifts)
     unsigned xmask, ymask;  // bit e set: slot e can be non-zero for SOME thread (x / y input)
-    long long t_point;      // float2 elements of T per source point = nt*rows*4
+    long long t_point;      // float2 elements of T per source point = ceil(pn/tc)*rows*tc
 };
 
 template <int LOG2N>
@@ -37,14 +38,18 @@ struct Launch {
 #define LITHO_NBUF 1
 #endif
     static constexpr int NBUF = (LOG2N <= 12) ? LITHO_NBUF : 1;
-    static constexpr size_t LDS_BYTES = sizeof(float2) * (size_t)L * NBUF * F::LDS_LINE;
+    static constexpr size_t LDS_EXCH = (size_t)L * NBUF * F::LDS_LINE;          // float2 slots of the exchange buffers
+    static constexpr size_t LDS_BYTES = sizeof(float2) * (LDS_EXCH + F::LDS_TW);   // + the twiddle tables
     // launch_bounds second argument = waves per SIMD we want resident: LITHO_WG_PER_CU workgroups per CU
     // up to N = 4096 (256 threads each), one above.  Measured at 2048^2: one LDS buffer (extra barrier) with 3
     // workgroups per CU beats two buffers with 2 by 7 %.
 #ifndef LITHO_WG_PER_CU
 #define LITHO_WG_PER_CU 3
 #endif
-    static constexpr int WAVES = (THREADS / 256 > 0 ? THREADS / 256 : 1) * (LOG2N <= 12 ? LITHO_WG_PER_CU : 1);
+    // N = 8192 (512 threads, 78 KB LDS): two workgroups per CU, otherwise every barrier idles the CU
+    // (measured at 4096^2: y-pass 96 -> 58 us/point).  N = 16384 needs 147 KB LDS: one.
+    static constexpr int WG_PER_CU = LOG2N <= 12 ? LITHO_WG_PER_CU : (LOG2N == 13 ? 2 : 1);
+    static constexpr int WAVES = (THREADS / 256 > 0 ? THREADS / 256 : 1) * WG_PER_CU;
     // Software prefetch of the next line's inputs: measured SLOWER on gfx950 (the extra live registers
     // spill: 35.9 vs 28.7 us/point at 2048^2), so it is off unless a build asks for it.
 #ifdef LITHO_PREFETCH
@@ -86,6 +91,13 @@ __device__ __forceinline__ void buf_store_c64(__amdgpu_buffer_rsrc_t r, unsigned
     __builtin_amdgcn_raw_buffer_store_b64(w, r, off, 0, 0);
 }
 
+// float2 offset of (row a, column q) inside one source point's T block
+__device__ __forceinline__ unsigned t_offset(const PassGeom& g, unsigned a, unsigned q) {
+    return ((((q >> g.tcl) * g.rows + a) << g.tcl) + (q & ((1u << g.tcl) - 1u)));
+}
+
+__device__ __forceinline__ void diag_keep(float2 v, unsigned o) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(o)); }
+
 // ----------------------------------------------------------------------------------
 // x-pass (no wrapping shift): A = P[box] * M[box + shift], rows of the support box ->
 // T[s][tile][row][4].  One workgroup = one row of the box for a CHUNK of source points: the
@@ -106,9 +118,20 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
     float2* lds = smem + (size_t)lg * LC::NBUF * F::LDS_LINE;
 
     typename F::Twiddles tw;
-    F::load_twiddles(tw, twtab, lt);
+    F::load_twiddles(tw, twtab, lt, smem + LC::LDS_EXCH, threadIdx.x, LC::THREADS);
 
-    const int a = blockIdx.x * LC::L + lg;
+    // XCD-aware row mapping.  A 128-byte line of T holds 4 consecutive rows x 4 columns, and the
+    // dispatcher deals consecutive workgroups round-robin over the 8 XCDs (private L2s): with the
+    // identity mapping the four quarters of every line are written from four different L2s and each
+    // one evicts a partial line (measured: 3.7 of 8.5 us/point).  Blocks b, b+8, b+16, b+24 run on the
+    // same XCD back to back, so they get rows 4j..4j+3 and the line is completed inside one L2.
+    int a;
+    if constexpr (LC::L == 1) {
+        const int b = blockIdx.x, xcd = b & 7, i = b >> 3;
+        a = (i >> 2) * 32 + xcd * 4 + (i & 3);
+    } else {
+        a = blockIdx.x * LC::L + lg;
+    }
     const bool active = a < g.rows;
     const int r = g.ky0 + g.c + a;                            // row of P inside its support box
     const size_t plane_bytes = (size_t)g.pn * g.pn * sizeof(float2);
@@ -133,7 +156,7 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
             int u;
             const bool ok = centred_index(lt + F::T * m, F::N, -g.c, g.pn - g.c, u) && active;
             const unsigned q = (unsigned)(u + g.c);
-            toff[m] = ok ? (((q >> 2) * g.rows + a) * 4u + (q & 3u)) * 8u : BUF_OOB;
+            toff[m] = ok ? t_offset(g, a, q) * 8u : BUF_OOB;
         }
     });
 
@@ -146,7 +169,11 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
         static_for<0, 16>([&](auto e_) {
             constexpr int e = decltype(e_)::value;
             if constexpr ((IN >> e) & 1u)
+#ifdef LITHO_DIAG_XNOLOAD
+                mv[e] = make_float2((float)((mrow + koff[e]) & 1023u), 1.0f);
+#else
                 mv[e] = buf_load_c64(rM, koff[e] != BUF_OOB ? (mrow + koff[e]) * 8u : BUF_OOB);
+#endif
         });
     };
 
@@ -167,7 +194,13 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
             make_rsrc(Tbuf + (size_t)s * g.t_point, (size_t)g.t_point * sizeof(float2));
         static_for<0, 16>([&](auto m_) {
             constexpr int m = decltype(m_)::value;
+#ifdef LITHO_DIAG_XNOSTORE
+            if constexpr ((OUT >> m) & 1u) diag_keep(x[m], toff[m]);
+#elif defined(LITHO_DIAG_XSTORE_L2)
+            if constexpr ((OUT >> m) & 1u) buf_store_c64(rT, toff[m] == BUF_OOB ? BUF_OOB : (toff[m] & 0xFFFFFu), x[m]);
+#else
             if constexpr ((OUT >> m) & 1u) buf_store_c64(rT, toff[m], x[m]);
+#endif
         });
         if constexpr (!(PRUNED && LC::PREFETCH)) {
             if (s + 1 < s_end) load_window(s + 1);
@@ -190,7 +223,7 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
     float2* lds = smem + (size_t)lg * LC::NBUF * F::LDS_LINE;
 
     typename F::Twiddles tw;
-    F::load_twiddles(tw, twtab, lt);
+    F::load_twiddles(tw, twtab, lt, smem + LC::LDS_EXCH, threadIdx.x, LC::THREADS);
 
     const int s = blockIdx.y;
     const int a = blockIdx.x * LC::L + lg;
@@ -207,14 +240,12 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
     int flip = 0;
     F::template run<LC::NBUF>(x, tw, lds, lt, flip);
 
-    float2* trow = Tbuf + (size_t)s * g.t_point + (size_t)a * 4;
-    const size_t tile_stride = (size_t)g.rows * 4;
+    float2* tpt = Tbuf + (size_t)s * g.t_point;
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
         int u;
         if (centred_index(lt + F::T * m, F::N, -g.c, g.pn - g.c, u) && active) {
-            const int q = u + g.c;
-            trow[(size_t)(q >> 2) * tile_stride + (q & 3)] = x[m];
+            tpt[t_offset(g, a, (unsigned)(u + g.c))] = x[m];
         }
     }
 }
@@ -282,7 +313,7 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
     float2* lds = smem + (size_t)lg * LC::NBUF * F::LDS_LINE;
 
     typename F::Twiddles tw;
-    F::load_twiddles(tw, twtab, lt);
+    F::load_twiddles(tw, twtab, lt, smem + LC::LDS_EXCH, threadIdx.x, LC::THREADS);
 
     const int tile = blockIdx.x * LC::L + lg;
     const bool active = tile < g.nt;
@@ -302,7 +333,7 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
         if constexpr ((IN >> e) & 1u) {
             int k;
             const bool ok = centred_index(lt + F::T * e, F::N, g.ky0, g.ky1, k) && active;
-            voff[e] = ok ? ((unsigned)tile * g.rows + (unsigned)(k - g.ky0)) * 32u : BUF_OOB;
+            voff[e] = ok ? t_offset(g, (unsigned)(k - g.ky0), (unsigned)tile * 4u) * 8u : BUF_OOB;
         }
     });
     float2 nx[16];
@@ -311,7 +342,11 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
             make_rsrc(Tbuf + (size_t)s * g.t_point, (size_t)g.t_point * sizeof(float2));
         static_for<0, 16>([&](auto e_) {
             constexpr int e = decltype(e_)::value;
+#ifdef LITHO_DIAG_YNOLOAD
+            if constexpr ((IN >> e) & 1u) nx[e] = make_float2(1.0f + 0.001f * e, 0.5f);
+#else
             if constexpr ((IN >> e) & 1u) nx[e] = buf_load_c64(rT, voff[e] + cidx * 8u);
+#endif
         });
     };
 
@@ -371,10 +406,9 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
     const int lt = threadIdx.x % F::T, lg = threadIdx.x / F::T;
     float2* lds = smem + (size_t)lg * LC::NBUF * F::LDS_LINE;
     typename F::Twiddles tw;
-    F::load_twiddles(tw, twtab, lt);
+    F::load_twiddles(tw, twtab, lt, smem + LC::LDS_EXCH, threadIdx.x, LC::THREADS);
     const int tile = blockIdx.x * LC::L + lg;
     const bool active = tile < g.nt;
-    const float2* tt = Tbuf + (size_t)(active ? tile : 0) * g.rows * 4;
     int flip = 0;
     for (int cidx = 0; cidx < 4; ++cidx) {
         float2 x[16];
@@ -382,7 +416,7 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
         for (int e = 0; e < 16; ++e) {
             int k;
             const bool ok = centred_index(lt + F::T * e, F::N, g.ky0, g.ky1, k) && active;
-            x[e] = ok ? tt[(size_t)(k - g.ky0) * 4 + cidx] : make_float2(0.f, 0.f);
+            x[e] = ok ? Tbuf[t_offset(g, (unsigned)(k - g.ky0), (unsigned)tile * 4u + cidx)] : make_float2(0.f, 0.f);
         }
         F::template run<LC::NBUF>(x, tw, lds, lt, flip);
         const int qx = tile * 4 + cidx;
@@ -430,7 +464,8 @@ struct SizeImpl {
         auto kern = k_xpass_abbe<LOG2N, RL, PRUNED>;
         hipError_t e = set_lds(kern, LC::LDS_BYTES);
         if (e != hipSuccess) return e;
-        dim3 grid((g.rows + LC::L - 1) / LC::L, (nb + chunk - 1) / chunk);
+        // L == 1: grid.x padded to a multiple of 32 for the XCD-aware row mapping in the kernel
+        dim3 grid(LC::L == 1 ? (g.rows + 31) / 32 * 32 : (g.rows + LC::L - 1) / LC::L, (nb + chunk - 1) / chunk);
         hipLaunchKernelGGL(kern, grid, dim3(LC::THREADS), LC::LDS_BYTES, st, P, M, shifts, T, tw, g, nb, chunk);
         return hipGetLastError();
     }

@@ -103,6 +103,12 @@ __device__ __forceinline__ void lds_barrier() {
     __syncthreads();
     return;
 #endif
+#ifdef LITHO_DIAG_NOBARRIER            // timing diagnostic only: results are wrong
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    return;
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
@@ -119,28 +125,57 @@ struct LineFFT {
     static constexpr int B1 = E / R1;              // leading-pass butterflies per thread
     static constexpr int EXCH = P16 - 1 + (R1 > 1 ? 1 : 0);   // LDS exchanges per transform
     static constexpr int LDS_LINE = N + LITHO_LDS_PAD * (N / 16);    // float2 slots per buffer per line
-    // Radix-16 pass p has Ns = R1 * 16^p; it needs twiddles iff Ns > 1.
-    static constexpr int NTW = P16 - (R1 == 1 ? 1 : 0);
+    // Radix-16 pass p works on sub-transforms of length Ns(p) = R1 * 16^p and needs twiddles
+    // w_{16 Ns}^{k r}, k = t mod Ns, iff Ns > 1.  A pass with Ns <= 64 has only Ns distinct
+    // twiddle sets: those live in a small LDS table shared by the workgroup (<= 7.7 KB); only the
+    // last pass of a large transform (Ns > 64) keeps its 15 twiddles in registers.  That frees 30
+    // VGPRs per thread compared with holding every set in registers.
+    static constexpr int ns_of(int p) { return R1 << (4 * p); }
+    static constexpr bool tw_needed(int p) { return ns_of(p) > 1; }
+    static constexpr bool tw_in_lds(int p) { return tw_needed(p) && ns_of(p) <= 64; }
+    static constexpr bool tw_in_reg(int p) { return tw_needed(p) && ns_of(p) > 64; }
+    static constexpr int lds_tw_offset(int p) {          // float2 offset of pass p's table
+        int off = 0;
+        for (int q = 0; q < p; ++q) if (tw_in_lds(q)) off += ns_of(q) * 15;
+        return off;
+    }
+    static constexpr int LDS_TW = lds_tw_offset(P16);     // float2 entries of the LDS twiddle tables
+    static constexpr int nreg_sets() { int n = 0; for (int p = 0; p < P16; ++p) n += tw_in_reg(p) ? 1 : 0; return n; }
+    static constexpr int reg_index(int p) { int n = 0; for (int q = 0; q < p; ++q) n += tw_in_reg(q) ? 1 : 0; return n; }
+    static constexpr int NTW = nreg_sets();
 
     struct Twiddles {
         float2 w[NTW > 0 ? NTW : 1][15];
+        const float2* lds;       // the workgroup's LDS twiddle tables
     };
 
-    // table[n] = exp(+2 pi i n / N); SIGN < 0 conjugates on the fly.
-    __device__ static __forceinline__ void load_twiddles(Twiddles& tw, const float2* __restrict__ table, int t) {
-        int ns = (R1 == 1) ? 16 : R1;
-#pragma unroll
-        for (int p = 0; p < NTW; ++p) {
-            const int k = t & (ns - 1);
-            const int step = k * (N / (16 * ns));
-#pragma unroll
-            for (int r = 1; r < 16; ++r) {
-                float2 w = table[step * r];
-                if (SIGN < 0) w.y = -w.y;
-                tw.w[p][r - 1] = w;
+    // table[n] = exp(+2 pi i n / N); SIGN < 0 conjugates on the fly.  Fills the LDS tables
+    // cooperatively (call with every thread of the workgroup, then lds_barrier) and the
+    // register-resident set of thread t.
+    __device__ static __forceinline__ void load_twiddles(Twiddles& tw, const float2* __restrict__ table, int t,
+                                                         float2* lds_tables, int wg_tid, int wg_threads) {
+        static_for<0, P16>([&](auto p_) {
+            constexpr int p = decltype(p_)::value;
+            constexpr int ns = ns_of(p);
+            if constexpr (tw_in_lds(p)) {
+                for (int i = wg_tid; i < ns * 15; i += wg_threads) {
+                    const int k = i / 15, r = i - k * 15 + 1;
+                    float2 w = table[k * r * (N / (16 * ns))];
+                    if (SIGN < 0) w.y = -w.y;
+                    lds_tables[lds_tw_offset(p) + i] = w;
+                }
+            } else if constexpr (tw_in_reg(p)) {
+                const int k = t & (ns - 1);
+                const int step = k * (N / (16 * ns));
+                static_for<1, 16>([&](auto r) {
+                    float2 w = table[step * decltype(r)::value];
+                    if (SIGN < 0) w.y = -w.y;
+                    tw.w[reg_index(p)][decltype(r)::value - 1] = w;
+                });
             }
-            ns *= 16;
-        }
+        });
+        tw.lds = lds_tables;
+        lds_barrier();
     }
 
     // Padded LDS slot of (i + off) given the padded slot of i, for the access patterns below:
@@ -148,9 +183,6 @@ struct LineFFT {
     // the low 4 bits of i (true for every pattern used here: see the comments at the call sites).
     // `off` is a compile-time constant, so each LDS access is one base register + an immediate.
     static constexpr int pad_off(int off) { return off + LITHO_LDS_PAD * (off >> 4); }
-
-    // Radix-16 pass p works on sub-transforms of length Ns(p) = R1 * 16^p.
-    static constexpr int ns_of(int p) { return R1 << (4 * p); }
 
     // x[e] holds sample n = t + T*e on entry and output bin n = t + T*e on exit.
     // lds: this line's two exchange buffers (2 * LDS_LINE float2) when NBUF == 2, one when NBUF == 1.
@@ -183,10 +215,12 @@ struct LineFFT {
             flip ^= 1;
         }
         static_for<0, P16>([&](auto p) {
-            constexpr int twi = p - (R1 == 1 ? 1 : 0);
             constexpr int ns = ns_of(decltype(p)::value);
-            if constexpr (twi >= 0) {
-                static_for<1, 16>([&](auto r) { x[r] = cmul(x[r], tw.w[twi][r - 1]); });
+            if constexpr (tw_in_reg(decltype(p)::value)) {
+                static_for<1, 16>([&](auto r) { x[r] = cmul(x[r], tw.w[reg_index(decltype(p)::value)][r - 1]); });
+            } else if constexpr (tw_in_lds(decltype(p)::value)) {
+                const float2* tp = tw.lds + lds_tw_offset(decltype(p)::value) + (t & (ns - 1)) * 15;
+                static_for<1, 16>([&](auto r) { x[r] = cmul(x[r], tp[decltype(r)::value - 1]); });
             }
             Dft<16, SIGN>::run(x);
             if constexpr (p < P16 - 1) {
@@ -196,10 +230,18 @@ struct LineFFT {
                 // ns >= 16; for ns < 16, k < ns and ns | 16, so k + m*ns never carries differently from m*ns.
                 const int k = t & (ns - 1);
                 float2* const wr0 = buf + lds_pad((t - k) * 16 + k);
+#ifndef LITHO_DIAG_NOLDSWRITE
                 static_for<0, 16>([&](auto m) { wr0[pad_off(decltype(m)::value * ns)] = x[m]; });
+#else
+                wr0[0] = x[15];
+#endif
                 lds_barrier();
                 float2* const rd = rd0 + (buf - lds);
+#ifndef LITHO_DIAG_NOLDSREAD
                 static_for<0, 16>([&](auto r) { x[r] = rd[pad_off(decltype(r)::value * T)]; });
+#else
+                x[0] = cadd(x[0], rd[0]);
+#endif
                 flip ^= 1;
             }
         });

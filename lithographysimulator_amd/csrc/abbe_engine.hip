@@ -282,21 +282,6 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     PassGeom g;
     make_geom(g, pn, N, r0, c0, h, wdt, general);
 
-    // Batch = source points per x-pass/y-pass launch pair.  The intermediate T of one batch should stay
-    // resident in the 256 MiB Infinity Cache between the two passes (measured at 2048^2: 63 points = 1 GiB
-    // -> 28.7 us/point, 16 points = 270 MB -> 21.9), and a y-pass workgroup needs >= ~8 points to
-    // amortise its accumulator flush.
-    const size_t point_bytes = (size_t)g.t_point * sizeof(float2);
-    int64_t bs = (int64_t)(w.t_bytes / point_bytes);
-    int64_t bs_cache = (int64_t)(((size_t)288 << 20) / point_bytes);
-    if (bs_cache < 8) bs_cache = 8;
-    if (bs > bs_cache) bs = bs_cache;
-    const int bs_env = env_int("LITHO_ABBE_BATCH", 0);
-    if (bs_env > 0) bs = (bs_env < (int64_t)(w.t_bytes / point_bytes)) ? bs_env : (int64_t)(w.t_bytes / point_bytes);
-    if (bs < 1) return LITHO_E_WORKSPACE;
-    if (bs > 65535) bs = 65535;
-    int xchunk = env_int("LITHO_ABBE_XCHUNK", 4);      // source points per x-pass workgroup
-    if (xchunk < 1) xchunk = 1;
     // y-pass groups: the grid is (tile blocks) x G workgroups; pick the smallest G that makes it a whole
     // number of full-occupancy rounds (256 CUs x workgroups per CU), so no round runs part-empty.
     const int l2n = ilog2(N);
@@ -310,6 +295,27 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     if (g_env > 0) G = g_env;
     if (G < 1) G = 1;
     if (G > G_MAX) G = G_MAX;
+    // Batch = source points per x-pass/y-pass launch pair.  The intermediate T of one batch should stay
+    // resident in the 256 MiB Infinity Cache between the two passes (measured at 2048^2: 63 points = 1 GiB
+    // -> 28.7 us/point, 16 points = 270 MB -> 21.9), and a y-pass workgroup needs >= ~8 points to
+    // amortise its accumulator flush.
+    const size_t point_bytes = (size_t)g.t_point * sizeof(float2);
+    int64_t bs = (int64_t)(w.t_bytes / point_bytes);
+    int64_t bs_cache = (int64_t)(((size_t)288 << 20) / point_bytes);
+    if (bs_cache < 8) bs_cache = 8;
+    if (bs > bs_cache) bs = bs_cache;
+    const int bs_env = env_int("LITHO_ABBE_BATCH", 0);
+    if (bs_env > 0) bs = (bs_env < (int64_t)(w.t_bytes / point_bytes)) ? bs_env : (int64_t)(w.t_bytes / point_bytes);
+    if (bs < 1) return LITHO_E_WORKSPACE;
+    if (bs > 65535) bs = 65535;
+    // Balance: every y-pass group gets the same number of points (batch multiple of G) and the x-pass
+    // chunks divide the batch evenly (chunk = divisor of the batch nearest 4).
+    if (bs_env <= 0 && bs > G) bs -= bs % G;
+    int xchunk = env_int("LITHO_ABBE_XCHUNK", 0);       // source points per x-pass workgroup
+    if (xchunk <= 0) {
+        xchunk = 4;
+        for (int cand : {4, 5, 3, 6, 2}) if (bs % cand == 0) { xchunk = cand; break; }
+    }
     const size_t slab_plane = (size_t)g.nt * 4 * pn;
     const SizeOps* ops = size_ops(ilog2(N));
     if (!ops) return LITHO_E_ARG;

@@ -132,8 +132,11 @@ struct LineFFT {
     // VGPRs per thread compared with holding every set in registers.
     static constexpr int ns_of(int p) { return R1 << (4 * p); }
     static constexpr bool tw_needed(int p) { return ns_of(p) > 1; }
-    static constexpr bool tw_in_lds(int p) { return tw_needed(p) && ns_of(p) <= 64; }
-    static constexpr bool tw_in_reg(int p) { return tw_needed(p) && ns_of(p) > 64; }
+#ifndef LITHO_LDS_TW_MAXNS
+#define LITHO_LDS_TW_MAXNS 64
+#endif
+    static constexpr bool tw_in_lds(int p) { return tw_needed(p) && ns_of(p) <= LITHO_LDS_TW_MAXNS; }
+    static constexpr bool tw_in_reg(int p) { return tw_needed(p) && ns_of(p) > LITHO_LDS_TW_MAXNS; }
     static constexpr int lds_tw_offset(int p) {          // float2 offset of pass p's table
         int off = 0;
         for (int q = 0; q < p; ++q) if (tw_in_lds(q)) off += ns_of(q) * 15;

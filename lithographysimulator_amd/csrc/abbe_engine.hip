@@ -287,7 +287,9 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     const int l2n = ilog2(N);
     const int lines_per_wg = (N / 16 >= 64) ? 1 : 64 / (N / 16);
     const int tile_blocks = (g.nt + lines_per_wg - 1) / lines_per_wg;
-    const int resident = 256 * (l2n <= 12 ? 3 : (l2n == 13 ? 2 : 1));
+    // (the wave-per-line y-pass used at 2048^2 keeps 2 workgroups per CU resident)
+    const bool w64_shape = (N == 4096 && pn == 2048 && env_int("LITHO_ABBE_W64", 1));
+    const int resident = 256 * (w64_shape ? 2 : l2n <= 12 ? 3 : (l2n == 13 ? 2 : 1));
     int a_ = tile_blocks, b_ = resident;
     while (b_) { const int t_ = a_ % b_; a_ = b_; b_ = t_; }
     int G = resident / a_;
@@ -320,6 +322,7 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     const SizeOps* ops = size_ops(ilog2(N));
     if (!ops) return LITHO_E_ARG;
     const int variant = pick_variant(g);
+    const bool use_w64 = variant == 1 && N == 4096 && pn == 2048 && g.tcl == 2 && env_int("LITHO_ABBE_W64", 1);
     int64_t nx = 0;
     // profiling: ONE event per kernel boundary (E0 x E1 y E2 x E3 ...); consecutive events bracket
     // exactly one launch.  (Two events recorded back to back alias on ROCm, so no begin/end pairs.)
@@ -341,12 +344,15 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
             if (general) {
                 AbbeLoader ld{Pp, M, shifts + 2 * s0, nullptr, nullptr, 0, 0};
                 HIP_TRY(ops->xpass_general(ld, w.T, w.twtab, g, nb, st));
+            } else if (use_w64 && env_int("LITHO_ABBE_W64X", 0)) {
+                HIP_TRY(ops->xpass_w64(Pp, M, shifts + 2 * s0, w.T, w.twtab, g, nb, st));
             } else {
                 HIP_TRY(ops->xpass_abbe(variant, Pp, M, shifts + 2 * s0, w.T, w.twtab, g, nb, xchunk, st));
             }
             mark(0, nb);
             const int Geff = nb < G ? nb : G;
-            HIP_TRY(ops->ypass_acc(variant, w.T, w.slab, w.twtab, g, nb, Geff, st));
+            if (use_w64) HIP_TRY(ops->ypass_w64(w.T, w.slab, w.twtab, g, nb, Geff, st));
+            else HIP_TRY(ops->ypass_acc(variant, w.T, w.slab, w.twtab, g, nb, Geff, st));
             mark(1, nb);
             ++nx;
         }

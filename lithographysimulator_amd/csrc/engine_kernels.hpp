@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include "fft_core.hpp"
+#include "wave_fft.hpp"
 
 namespace litho {
 
@@ -394,6 +395,150 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
     });
 }
 
+// ----------------------------------------------------------------------------------
+// x-pass, wave-per-line variant for N = 4096, pn = 2048, pupil inside the unit disk, no wrapping
+// shift.  Work item = (group of 4 consecutive box rows, source point); the 4 waves of a workgroup
+// take the 4 rows, i.e. exactly the rows that share each 128-byte line of T, so every line is
+// completed inside one CU.  Each workgroup walks a contiguous range of items (row-group major), so
+// the grid is sized to the machine and the pupil row is re-read only when the row group changes.
+// ----------------------------------------------------------------------------------
+template <int LOG2N>
+__global__ __launch_bounds__(256, 2) void k_xpass_w64(
+    const float2* __restrict__ P, const float2* __restrict__ M, const int* __restrict__ shifts,
+    float2* __restrict__ Tbuf, const float2* __restrict__ twtab, PassGeom g, int nb, int items_per_wg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* lds = smem + wv * Wave4096::LDS_FLOATS;
+    Wave4096::LaneTwiddles tw;
+    Wave4096::load_lane_twiddles(tw, twtab, lane);
+
+    const int ngroups = (g.rows + 3) >> 2;
+    const int items = ngroups * nb;
+    const int i0 = blockIdx.x * items_per_wg;
+    const int i1 = min(items, i0 + items_per_wg);
+
+    // Live input slots j (sample n = lane + 64 j): k = lane + 64 j (j <= 8) or lane + 64 j - 4096 (j >= 56).
+    // The buffer descriptors are WINDOWED on the valid columns [kx0, kx1) of the current row, so the
+    // hardware range check is the validity test (a slot left of the window wraps to a huge unsigned
+    // offset) and every slot address is one base register + a compile-time constant.
+    const unsigned win_bytes = (unsigned)(g.kx1 - g.kx0) * 8u;
+    const unsigned vb = (unsigned)(lane - g.kx0) * 8u;
+    auto slot_off = [&](int j) { return vb + (unsigned)(j <= 8 ? 512 * j : 512 * j - 32768); };
+
+    float2 pv[64];
+    int cur_group = -1, a = 0, r = 0;
+    bool active = false;
+    for (int it = i0; it < i1; ++it) {
+        const int grp = it / nb, s = it - grp * nb;
+        if (grp != cur_group) {                                  // wave-uniform: new row group, reload the pupil row
+            cur_group = grp;
+            a = grp * 4 + wv;
+            active = a < g.rows;
+            r = g.ky0 + g.c + (active ? a : 0);
+            const __amdgpu_buffer_rsrc_t rP = make_rsrc(P + (size_t)r * g.pn + g.c + g.kx0, active ? win_bytes : 0u);
+            static_for<0, 64>([&](auto j_) {
+                constexpr int j = decltype(j_)::value;
+                if constexpr (j <= 8 || j >= 56) pv[j] = buf_load_c64(rP, slot_off(j));
+            });
+        }
+        if (!active) continue;                                   // whole wave idle: no workgroup barriers anywhere
+        const int dy = shifts[2 * s], dx = shifts[2 * s + 1];
+        const __amdgpu_buffer_rsrc_t rM = make_rsrc(M + (size_t)(r + dy) * g.pn + dx + g.c + g.kx0, win_bytes);
+        float2 x[64];
+        static_for<0, 64>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            if constexpr (j <= 8 || j >= 56) x[j] = cmul(pv[j], buf_load_c64(rM, slot_off(j)));
+            else x[j] = make_float2(0.f, 0.f);
+        });
+        Wave4096::run(x, tw, lds, lane);
+        // kept bins u in [-1024, 1024): k2 in 0..15 -> q = lane + 64 k2 + 1024 ; k2 in 48..63 -> q = lane + 64 (k2 - 48)
+        const __amdgpu_buffer_rsrc_t rT =
+            make_rsrc(Tbuf + (size_t)s * g.t_point, (size_t)g.t_point * sizeof(float2));
+        const unsigned vbase = (((unsigned)(lane >> 2) * g.rows + a) * 4u + (lane & 3u)) * 8u;
+        const unsigned kstride = 16u * g.rows * 32u;             // bytes between q and q + 64
+        static_for<0, 32>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            constexpr int k2 = i < 16 ? i : 32 + i;
+            constexpr int kk = i < 16 ? i + 16 : i - 16;         // (q - lane) / 64
+            buf_store_c64(rT, vbase + kk * kstride, x[br6(k2)]);
+        });
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// y-pass, wave-per-line variant for N = 4096, pn = 2048, pupil inside the unit disk: each of the
+// 4 waves of a workgroup owns ONE column of the 4-column tile and transforms it on its own
+// (wave_fft.hpp): no workgroup barriers, half the LDS traffic of the radix-16 engine.
+// ----------------------------------------------------------------------------------
+template <int LOG2N>
+__global__ __launch_bounds__(256, 2) void k_ypass_w64(
+    const float2* __restrict__ Tbuf, float* __restrict__ slab, const float2* __restrict__ twtab,
+    PassGeom g, int nb, int G)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* lds = smem + wv * Wave4096::LDS_FLOATS;
+    Wave4096::LaneTwiddles tw;
+    Wave4096::load_lane_twiddles(tw, twtab, lane);
+
+    const int tile = blockIdx.x, grp = blockIdx.y;
+    float acc[32];
+    static_for<0, 32>([&](auto i) { acc[i] = 0.f; });
+
+    // Live input slots j: k = lane + 64 j (j <= 8) or lane + 64 j - 4096 (j >= 56); T row a = k - ky0.
+    // The descriptor is windowed on this tile's rows ([tile][row][4] layout, 32 B per row), so the
+    // range check is the validity test and each slot is one base register + a constant.
+    const unsigned tile_bytes = (unsigned)g.rows * 32u;
+    const unsigned vb = (unsigned)(lane - g.ky0) * 32u + (unsigned)wv * 8u;
+    auto slot_off = [&](int j) { return vb + (unsigned)(j <= 8 ? 2048 * j : 2048 * j - 131072); };
+
+    float2 nx[64];                                      // next line's live slots (prefetch)
+    auto load_line = [&](int s) {
+        const __amdgpu_buffer_rsrc_t rT =
+            make_rsrc(Tbuf + (size_t)s * g.t_point + (size_t)tile * g.rows * 4, tile_bytes);
+        static_for<0, 64>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            if constexpr (j <= 8 || j >= 56) nx[j] = buf_load_c64(rT, slot_off(j));
+        });
+    };
+    if (grp < nb) load_line(grp);
+    for (int s = grp; s < nb; s += G) {
+        float2 x[64];
+        static_for<0, 64>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            if constexpr (j <= 8 || j >= 56) x[j] = nx[j];
+            else x[j] = make_float2(0.f, 0.f);
+        });
+#ifdef LITHO_W64_PREFETCH                            // measured: no gain (9.29 vs 9.15 us/point), off
+        if (s + G < nb) load_line(s + G);
+#endif
+        Wave4096::run(x, tw, lds, lane);
+        // kept bins: u in [-1024, 1024)  ->  k2 in 0..15 and 48..63
+        static_for<0, 32>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            constexpr int k2 = i < 16 ? i : 32 + i;
+            const float2 v = x[br6(k2)];
+            acc[i] = fmaf(v.x, v.x, fmaf(v.y, v.y, acc[i]));
+        });
+#ifndef LITHO_W64_PREFETCH
+        if (s + G < nb) load_line(s + G);
+#endif
+    }
+
+    const int qx = tile * 4 + wv;
+    float* srow = slab + ((size_t)grp * g.nt * 4 + qx) * g.pn;
+    static_for<0, 32>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        constexpr int k2 = i < 16 ? i : 32 + i;
+        const int n = lane + 64 * k2;
+        const int u = n < 2048 ? n : n - 4096;
+        srow[u + g.c] += acc[i];
+    });
+}
+
 // y-pass that writes the complex field instead (calculateFFTAerial, mask spectrum).
 template <int LOG2N, int SIGN>
 __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void k_ypass_field(
@@ -444,6 +589,11 @@ struct SizeOps {
                             int G, hipStream_t st);
     hipError_t (*ypass_field)(int sign, const float2* T, float2* field, const float2* tw, const PassGeom& g,
                               hipStream_t st);
+    // wave-per-line passes (N = 4096, pn = 2048, pruned only); hipErrorNotSupported for other sizes
+    hipError_t (*xpass_w64)(const float2* P, const float2* M, const int* shifts, float2* T, const float2* tw,
+                            const PassGeom& g, int nb, hipStream_t st);
+    hipError_t (*ypass_w64)(const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb, int G,
+                            hipStream_t st);
 };
 const SizeOps* size_ops(int log2n);      // nullptr outside 4..14
 
@@ -520,6 +670,37 @@ struct SizeImpl {
             default: return ya<-1, false>(T, slab, tw, g, nb, G, st);
         }
     }
+    static hipError_t xpass_w64(const float2* P, const float2* M, const int* shifts, float2* T, const float2* tw,
+                                const PassGeom& g, int nb, hipStream_t st)
+    {
+        if constexpr (LOG2N == 12) {
+            constexpr size_t lds = 4 * Wave4096::LDS_FLOATS * sizeof(float);
+            auto kern = k_xpass_w64<LOG2N>;
+            hipError_t e = set_lds(kern, lds);
+            if (e != hipSuccess) return e;
+            const int items = ((g.rows + 3) / 4) * nb;
+            const int wgs = items < 512 ? items : 512;               // 256 CUs x 2 resident workgroups
+            const int per = (items + wgs - 1) / wgs;
+            hipLaunchKernelGGL(kern, dim3((items + per - 1) / per), dim3(256), lds, st, P, M, shifts, T, tw, g, nb, per);
+            return hipGetLastError();
+        } else {
+            return hipErrorNotSupported;
+        }
+    }
+    static hipError_t ypass_w64(const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb, int G,
+                                hipStream_t st)
+    {
+        if constexpr (LOG2N == 12) {
+            constexpr size_t lds = 4 * Wave4096::LDS_FLOATS * sizeof(float);
+            auto kern = k_ypass_w64<LOG2N>;
+            hipError_t e = set_lds(kern, lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(g.nt, G), dim3(256), lds, st, T, slab, tw, g, nb, G);
+            return hipGetLastError();
+        } else {
+            return hipErrorNotSupported;
+        }
+    }
     static hipError_t ypass_field(int sign, const float2* T, float2* field, const float2* tw, const PassGeom& g,
                                   hipStream_t st)
     {
@@ -545,7 +726,8 @@ struct SizeImpl {
     {                                                                                                \
         static const SizeOps ops{&SizeImpl<L2>::xpass_abbe, &SizeImpl<L2>::xpass_general,            \
                                  &SizeImpl<L2>::xpass_real_fwd, &SizeImpl<L2>::ypass_acc,            \
-                                 &SizeImpl<L2>::ypass_field};                                        \
+                                 &SizeImpl<L2>::ypass_field, &SizeImpl<L2>::xpass_w64,               \
+                                 &SizeImpl<L2>::ypass_w64};                                          \
         return &ops;                                                                                 \
     }
 

@@ -288,7 +288,8 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     const int lines_per_wg = (N / 16 >= 64) ? 1 : 64 / (N / 16);
     const int tile_blocks = (g.nt + lines_per_wg - 1) / lines_per_wg;
     // (the wave-per-line y-pass used at 2048^2 keeps 2 workgroups per CU resident)
-    const bool w64_shape = (N == 4096 && pn == 2048 && env_int("LITHO_ABBE_W64", 1));
+    const bool w64_ok = (N == 4096 && pn == 2048) || (N == 8192 && pn == 4096 && env_int("LITHO_ABBE_W64_8192", 0));
+    const bool w64_shape = w64_ok && env_int("LITHO_ABBE_W64", 1);
     const int resident = 256 * (w64_shape ? 2 : l2n <= 12 ? 3 : (l2n == 13 ? 2 : 1));
     int a_ = tile_blocks, b_ = resident;
     while (b_) { const int t_ = a_ % b_; a_ = b_; b_ = t_; }
@@ -322,7 +323,7 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     const SizeOps* ops = size_ops(ilog2(N));
     if (!ops) return LITHO_E_ARG;
     const int variant = pick_variant(g);
-    const bool use_w64 = variant == 1 && N == 4096 && pn == 2048 && g.tcl == 2 && env_int("LITHO_ABBE_W64", 1);
+    const bool use_w64 = variant == 1 && w64_shape && g.tcl == 2;
     int64_t nx = 0;
     // profiling: ONE event per kernel boundary (E0 x E1 y E2 x E3 ...); consecutive events bracket
     // exactly one launch.  (Two events recorded back to back alias on ROCm, so no begin/end pairs.)
@@ -344,7 +345,7 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
             if (general) {
                 AbbeLoader ld{Pp, M, shifts + 2 * s0, nullptr, nullptr, 0, 0};
                 HIP_TRY(ops->xpass_general(ld, w.T, w.twtab, g, nb, st));
-            } else if (use_w64 && env_int("LITHO_ABBE_W64X", 0)) {
+            } else if (use_w64 && N == 4096 && env_int("LITHO_ABBE_W64X", 0)) {
                 HIP_TRY(ops->xpass_w64(Pp, M, shifts + 2 * s0, w.T, w.twtab, g, nb, st));
             } else {
                 HIP_TRY(ops->xpass_abbe(variant, Pp, M, shifts + 2 * s0, w.T, w.twtab, g, nb, xchunk, st));

@@ -468,74 +468,91 @@ __global__ __launch_bounds__(256, 2) void k_xpass_w64(
 }
 
 // ----------------------------------------------------------------------------------
-// y-pass, wave-per-line variant for N = 4096, pn = 2048, pupil inside the unit disk: each of the
-// 4 waves of a workgroup owns ONE column of the 4-column tile and transforms it on its own
-// (wave_fft.hpp): no workgroup barriers, half the LDS traffic of the radix-16 engine.
+// y-pass, wave-per-line variant for N = 4096 * D (D = 1, 2), pn = N/2, pupil inside the unit disk.
+// D = 1: each of the 4 waves of a workgroup owns one column of the 4-column tile and transforms it on
+// its own (wave_fft.hpp): no workgroup barriers, half the LDS traffic of the radix-16 engine.
+// D = 2: decimation in frequency, out[2v + p] = sum_n' ([x[n'] + (-1)^p x[n' + 4096]] w_N^(n' p)) w_4096^(n' v):
+// two independent 4096-point sub-transforms (even / odd bins) per column, one wave each -- the pruned
+// input makes the first butterfly trivial (at most one of x[n'], x[n'+4096] is non-zero), and the two
+// waves never exchange data.  A workgroup then covers 2 columns.
 // ----------------------------------------------------------------------------------
 template <int LOG2N>
 __global__ __launch_bounds__(256, 2) void k_ypass_w64(
     const float2* __restrict__ Tbuf, float* __restrict__ slab, const float2* __restrict__ twtab,
     PassGeom g, int nb, int G)
 {
+    static_assert(LOG2N == 12 || LOG2N == 13, "wave-per-line y-pass: N = 4096 or 8192");
+    constexpr int D = 1 << (LOG2N - 12);
+    constexpr int N = 1 << LOG2N;
+    constexpr int JLIVE = 8 * D;                       // live slots: j in [0, JLIVE] and [64 - JLIVE, 64)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float* lds = smem + wv * Wave4096::LDS_FLOATS;
     Wave4096::LaneTwiddles tw;
-    Wave4096::load_lane_twiddles(tw, twtab, lane);
+    // the sub-transform's own twiddles w_4096^(lane m) are every D-th entry of the w_N table
+    static_for<0, 8>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        tw.row[i] = twtab[D * lane * i];
+        tw.row[8 + i] = twtab[D * lane * 8 * i];
+    });
+    const int p = wv % D;                               // which residue of the output bins this wave makes
+    const int colw = wv / D;                            // column inside this workgroup's column group
+    const float2 tl = twtab[lane * p];                  // w_N^(lane p)  (1 for p = 0)
 
-    const int tile = blockIdx.x, grp = blockIdx.y;
+    const int tile = blockIdx.x / D, grp = blockIdx.y;
+    const int col = (blockIdx.x % D) * (4 / D) + colw;  // column inside the 4-column tile
     float acc[32];
     static_for<0, 32>([&](auto i) { acc[i] = 0.f; });
 
-    // Live input slots j: k = lane + 64 j (j <= 8) or lane + 64 j - 4096 (j >= 56); T row a = k - ky0.
-    // The descriptor is windowed on this tile's rows ([tile][row][4] layout, 32 B per row), so the
-    // range check is the validity test and each slot is one base register + a constant.
+    // Live input slots j (sub-transform sample n' = lane + 64 j): k = n' for j <= JLIVE, k = n' - 4096 (i.e.
+    // sample n' + N - 4096 of the full line) for j >= 64 - JLIVE; T row a = k - ky0.  The descriptor is
+    // windowed on this tile's rows ([tile][row][4] layout, 32 B per row): the range check is the validity test.
     const unsigned tile_bytes = (unsigned)g.rows * 32u;
-    const unsigned vb = (unsigned)(lane - g.ky0) * 32u + (unsigned)wv * 8u;
-    auto slot_off = [&](int j) { return vb + (unsigned)(j <= 8 ? 2048 * j : 2048 * j - 131072); };
+    const unsigned vb = (unsigned)(lane - g.ky0) * 32u + (unsigned)col * 8u;
+    auto slot_off = [&](int j) { return vb + (unsigned)(j <= JLIVE ? 2048 * j : 2048 * j - 131072); };
 
-    float2 nx[64];                                      // next line's live slots (prefetch)
-    auto load_line = [&](int s) {
+    for (int s = grp; s < nb; s += G) {
         const __amdgpu_buffer_rsrc_t rT =
             make_rsrc(Tbuf + (size_t)s * g.t_point + (size_t)tile * g.rows * 4, tile_bytes);
-        static_for<0, 64>([&](auto j_) {
-            constexpr int j = decltype(j_)::value;
-            if constexpr (j <= 8 || j >= 56) nx[j] = buf_load_c64(rT, slot_off(j));
-        });
-    };
-    if (grp < nb) load_line(grp);
-    for (int s = grp; s < nb; s += G) {
         float2 x[64];
         static_for<0, 64>([&](auto j_) {
             constexpr int j = decltype(j_)::value;
-            if constexpr (j <= 8 || j >= 56) x[j] = nx[j];
-            else x[j] = make_float2(0.f, 0.f);
+            if constexpr (j <= JLIVE || j >= 64 - JLIVE) {
+                float2 v = buf_load_c64(rT, slot_off(j));
+                if constexpr (D > 1) {
+                    // w_N^(n' p) = w_N^(lane p) * w_N^(64 j p), and (-1)^p for the upper half (q = 1)
+                    if (p) {
+                        constexpr int e = (64 * j) % N;                       // exponent of the constant factor
+                        constexpr double ang = 6.283185307179586476925 * e / N;
+                        constexpr float sgn = (j >= 64 - JLIVE) ? -1.f : 1.f;
+                        const float2 cj = make_float2(sgn * (float)__builtin_cos(ang), sgn * (float)__builtin_sin(ang));
+                        v = cmul(cmul(v, cj), tl);
+                    }
+                }
+                x[j] = v;
+            } else {
+                x[j] = make_float2(0.f, 0.f);
+            }
         });
-#ifdef LITHO_W64_PREFETCH                            // measured: no gain (9.29 vs 9.15 us/point), off
-        if (s + G < nb) load_line(s + G);
-#endif
         Wave4096::run(x, tw, lds, lane);
-        // kept bins: u in [-1024, 1024)  ->  k2 in 0..15 and 48..63
+        // kept bins: v in [-1024, 1024)  ->  k2 in 0..15 and 48..63
         static_for<0, 32>([&](auto i_) {
             constexpr int i = decltype(i_)::value;
             constexpr int k2 = i < 16 ? i : 32 + i;
             const float2 v = x[br6(k2)];
             acc[i] = fmaf(v.x, v.x, fmaf(v.y, v.y, acc[i]));
         });
-#ifndef LITHO_W64_PREFETCH
-        if (s + G < nb) load_line(s + G);
-#endif
     }
 
-    const int qx = tile * 4 + wv;
+    const int qx = tile * 4 + col;
     float* srow = slab + ((size_t)grp * g.nt * 4 + qx) * g.pn;
     static_for<0, 32>([&](auto i_) {
         constexpr int i = decltype(i_)::value;
         constexpr int k2 = i < 16 ? i : 32 + i;
         const int n = lane + 64 * k2;
-        const int u = n < 2048 ? n : n - 4096;
-        srow[u + g.c] += acc[i];
+        const int v = n < 2048 ? n : n - 4096;          // bin of the sub-transform
+        srow[D * v + p + g.c] += acc[i];                // bin u = D v + p of the full line
     });
 }
 
@@ -690,12 +707,13 @@ struct SizeImpl {
     static hipError_t ypass_w64(const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb, int G,
                                 hipStream_t st)
     {
-        if constexpr (LOG2N == 12) {
+        if constexpr (LOG2N == 12 || LOG2N == 13) {
             constexpr size_t lds = 4 * Wave4096::LDS_FLOATS * sizeof(float);
+            constexpr int D = 1 << (LOG2N - 12);
             auto kern = k_ypass_w64<LOG2N>;
             hipError_t e = set_lds(kern, lds);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, dim3(g.nt, G), dim3(256), lds, st, T, slab, tw, g, nb, G);
+            hipLaunchKernelGGL(kern, dim3(g.nt * D, G), dim3(256), lds, st, T, slab, tw, g, nb, G);
             return hipGetLastError();
         } else {
             return hipErrorNotSupported;

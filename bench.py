@@ -133,7 +133,7 @@ def main():
         except Exception:
             traffic = None
     both_ms = kern["xpass"]["total_ms"] + kern["ypass"]["total_ms"]
-    roofline = {"bound": "hbm", "kernel": "k_ypass_acc" if dom == "ypass" else "k_xpass_abbe",
+    roofline = {"bound": "hbm", "kernel": prof["ypass_kernel"] if dom == "ypass" else "k_xpass_abbe",
                 "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": kern[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
                 "avg_launch_ms": kern[dom]["avg_launch_ms"],

@@ -373,6 +373,7 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
             }
         }
         for (auto& m : marks) (void)hipEventDestroy(m.ev);
+        g_profile[6] = use_w64 ? 1 : 0;
     }
     g_last_plan[0] = general; g_last_plan[1] = r0; g_last_plan[2] = c0; g_last_plan[3] = h;
     g_last_plan[4] = wdt; g_last_plan[5] = bs; g_last_plan[6] = nx; g_last_plan[7] = variant;

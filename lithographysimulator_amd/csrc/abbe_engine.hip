@@ -290,7 +290,7 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     // (the wave-per-line y-pass used at 2048^2 keeps 2 workgroups per CU resident)
     const bool w64_ok = (N == 4096 && pn == 2048) || (N == 8192 && pn == 4096 && env_int("LITHO_ABBE_W64_8192", 0));
     const bool w64_shape = w64_ok && env_int("LITHO_ABBE_W64", 1);
-    const int resident = 256 * (w64_shape ? 2 : l2n <= 12 ? 3 : (l2n == 13 ? 2 : 1));
+    const int resident = 256 * (w64_shape ? (N == 4096 ? 2 : 1) : l2n <= 12 ? 3 : (l2n == 13 ? 2 : 1));
     int a_ = tile_blocks, b_ = resident;
     while (b_) { const int t_ = a_ % b_; a_ = b_; b_ = t_; }
     int G = resident / a_;

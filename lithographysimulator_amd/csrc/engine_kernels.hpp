@@ -474,10 +474,11 @@ __global__ __launch_bounds__(256, 2) void k_xpass_w64(
 // D = 2: decimation in frequency, out[2v + p] = sum_n' ([x[n'] + (-1)^p x[n' + 4096]] w_N^(n' p)) w_4096^(n' v):
 // two independent 4096-point sub-transforms (even / odd bins) per column, one wave each -- the pruned
 // input makes the first butterfly trivial (at most one of x[n'], x[n'+4096] is non-zero), and the two
-// waves never exchange data.  A workgroup then covers 2 columns.
+// waves never exchange data.  The workgroup is then 8 waves (4 columns x 2 residues), so that every consumer
+// of a T tile sits on one CU.
 // ----------------------------------------------------------------------------------
 template <int LOG2N>
-__global__ __launch_bounds__(256, 2) void k_ypass_w64(
+__global__ __launch_bounds__(256 << (LOG2N - 12), 2) void k_ypass_w64(
     const float2* __restrict__ Tbuf, float* __restrict__ slab, const float2* __restrict__ twtab,
     PassGeom g, int nb, int G)
 {
@@ -497,11 +498,10 @@ __global__ __launch_bounds__(256, 2) void k_ypass_w64(
         tw.row[8 + i] = twtab[D * lane * 8 * i];
     });
     const int p = wv % D;                               // which residue of the output bins this wave makes
-    const int colw = wv / D;                            // column inside this workgroup's column group
+    const int col = wv / D;                             // column inside the 4-column tile
     const float2 tl = twtab[lane * p];                  // w_N^(lane p)  (1 for p = 0)
 
-    const int tile = blockIdx.x / D, grp = blockIdx.y;
-    const int col = (blockIdx.x % D) * (4 / D) + colw;  // column inside the 4-column tile
+    const int tile = blockIdx.x, grp = blockIdx.y;
     float acc[32];
     static_for<0, 32>([&](auto i) { acc[i] = 0.f; });
 
@@ -708,12 +708,12 @@ struct SizeImpl {
                                 hipStream_t st)
     {
         if constexpr (LOG2N == 12 || LOG2N == 13) {
-            constexpr size_t lds = 4 * Wave4096::LDS_FLOATS * sizeof(float);
             constexpr int D = 1 << (LOG2N - 12);
+            constexpr size_t lds = 4 * D * Wave4096::LDS_FLOATS * sizeof(float);
             auto kern = k_ypass_w64<LOG2N>;
             hipError_t e = set_lds(kern, lds);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, dim3(g.nt * D, G), dim3(256), lds, st, T, slab, tw, g, nb, G);
+            hipLaunchKernelGGL(kern, dim3(g.nt, G), dim3(256 * D), lds, st, T, slab, tw, g, nb, G);
             return hipGetLastError();
         } else {
             return hipErrorNotSupported;

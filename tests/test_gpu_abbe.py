@@ -263,3 +263,60 @@ def test_properties_2048(L, dev):
     dy, dx = [int(v) for v in sel[0].tolist()]
     A = torch.roll(pf, shifts=(dy, dx), dims=(0, 1)) * mft
     assert float(one.double().sum()) <= float(N) ** 2 * float((A.abs().double() ** 2).sum()) * (1 + 1e-5)
+
+
+# ------------------------------------------------------------------ kernel variants must agree with each other
+def _with_env(monkeypatch, L, env, fn):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    try:
+        return fn()
+    finally:
+        for k in env:
+            monkeypatch.delenv(k, raising=False)
+
+
+def test_wave_per_line_and_radix16_ypass_agree_2048(L, dev, monkeypatch):
+    """The default y-pass at 2048^2 is the wave-per-line kernel (k_ypass_w64); the radix-16 workgroup
+    kernel (k_ypass_acc), the generic runtime-predicated kernels and the general (modular) path must all
+    give the same image on the same inputs."""
+    from lithographysimulator_amd import _native as nat
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    pn = 2048
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    pf = L.Pupil(pn, WL, NA, f16([0, 0, 0, 0, 100]), dev).generatePupilFunction()
+    sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateAnnular(), pn)
+    sel = sh[(torch.arange(9, device=dev) * sh.shape[0]) // 9]
+    nat.set_profiling(True)
+    try:
+        ref = L.abbeIntensity(mft, pf, sel, N).cpu()
+        assert nat.last_profile()["ypass_kernel"] == "k_ypass_w64" and nat.last_plan()["variant"] == 1
+        r16 = _with_env(monkeypatch, L, {"LITHO_ABBE_W64": "0"}, lambda: L.abbeIntensity(mft, pf, sel, N).cpu())
+        assert nat.last_profile()["ypass_kernel"] == "k_ypass_acc"
+    finally:
+        nat.set_profiling(False)
+    assert rel_max(r16, ref) < 2e-6
+    generic = _with_env(monkeypatch, L, {"LITHO_ABBE_FORCE_GENERIC": "1"}, lambda: L.abbeIntensity(mft, pf, sel[:3], N).cpu())
+    assert nat.last_plan()["variant"] == -1
+    general = _with_env(monkeypatch, L, {"LITHO_ABBE_FORCE_GENERAL": "1"}, lambda: L.abbeIntensity(mft, pf, sel[:3], N).cpu())
+    assert nat.last_plan()["general"] == 1
+    part = L.abbeIntensity(mft, pf, sel[:3], N).cpu()
+    assert rel_max(generic, part) < 2e-6 and rel_max(general, part) < 2e-6
+    wx = _with_env(monkeypatch, L, {"LITHO_ABBE_W64X": "1"}, lambda: L.abbeIntensity(mft, pf, sel[:3], N).cpu())
+    assert rel_max(wx, part) < 2e-6                     # the (slower, opt-in) wave-per-line x-pass
+
+
+def test_optin_wave_kernel_4096_agrees(L, dev, monkeypatch):
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    pn = 4096
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    pf = L.Pupil(pn, WL, NA, f16(DEMO_AB), dev).generatePupilFunction()
+    sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateQuasar(4, -math.pi / 8), pn)
+    sel = sh[(torch.arange(3, device=dev) * sh.shape[0]) // 3]
+    ref = L.abbeIntensity(mft, pf, sel, N).cpu()
+    w64 = _with_env(monkeypatch, L, {"LITHO_ABBE_W64_8192": "1"}, lambda: L.abbeIntensity(mft, pf, sel, N).cpu())
+    assert rel_max(w64, ref) < 2e-6

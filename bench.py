@@ -145,7 +145,7 @@ def main():
 
     out = {"metric": "Abbe source-points x image-pixels per second", "value": value, "unit": "source-pt*px/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 (complex64)",
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic",
            "config": {"workload": f"BASELINE {args.workload}: {desc}", "pn": pn, "fft_n": N, "source_points": S,
                       "points_per_rank": math.ceil(S / world), "pixel_size": PS, "wavelength": WL, "NA": NA,

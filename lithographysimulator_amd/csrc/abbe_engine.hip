@@ -124,7 +124,14 @@ struct Workspace {
     size_t t_bytes;
 };
 
-static constexpr int G_MAX = 8;
+// y-pass groups = private partial images (slabs).  Up to 8 for large images; small images can afford more
+// (their y-pass grid would otherwise be a handful of workgroups): as many as fit in 128 MiB, at most 64.
+static int g_cap(int pn)
+{
+    const size_t one = (size_t)((pn + 3) / 4) * 4 * pn * sizeof(float);
+    size_t n = ((size_t)128 << 20) / one;
+    return n < 8 ? 8 : (n > 64 ? 64 : (int)n);
+}
 static constexpr size_t T_BUDGET_MAX = (size_t)1 << 30;
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -144,7 +151,7 @@ static size_t workspace_bytes(int pn, int N)
     const size_t nt = (pn + 3) / 4;
     size_t b = 256;
     b += align_up((size_t)N * sizeof(float2), 256);
-    b += align_up((size_t)G_MAX * nt * 4 * pn * sizeof(float), 256);
+    b += align_up((size_t)g_cap(pn) * nt * 4 * pn * sizeof(float), 256);
     b += align_up(t_budget(pn), 256);
     return b;
 }
@@ -156,7 +163,7 @@ static bool carve(void* ws, size_t bytes, int pn, int N, Workspace& w)
     unsigned char* p = (unsigned char*)ws;
     w.plan = (int*)p; p += 256;
     w.twtab = (float2*)p; p += align_up((size_t)N * sizeof(float2), 256);
-    w.slab = (float*)p; p += align_up((size_t)G_MAX * nt * 4 * pn * sizeof(float), 256);
+    w.slab = (float*)p; p += align_up((size_t)g_cap(pn) * nt * 4 * pn * sizeof(float), 256);
     w.T = (float2*)p;
     w.t_bytes = t_budget(pn);
     return true;
@@ -297,7 +304,7 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     const int g_env = env_int("LITHO_ABBE_GROUPS", 0);
     if (g_env > 0) G = g_env;
     if (G < 1) G = 1;
-    if (G > G_MAX) G = G_MAX;
+    if (G > g_cap(pn)) G = g_cap(pn);
     // Batch = source points per x-pass/y-pass launch pair.  The intermediate T of one batch should stay
     // resident in the 256 MiB Infinity Cache between the two passes (measured at 2048^2: 63 points = 1 GiB
     // -> 28.7 us/point, 16 points = 270 MB -> 21.9), and a y-pass workgroup needs >= ~8 points to
@@ -429,7 +436,7 @@ static int mask_spectrum(const int16_t* geo, int pn, double eps, int N, float2* 
     const int j0 = pW > 0 ? pW : 0;
     const int j1 = (pW + ns < N) ? pW + ns : N;
     const size_t nt = (pn + 3) / 4;
-    if ((size_t)ns * ns * sizeof(float) > (size_t)G_MAX * nt * 4 * pn * sizeof(float)) return LITHO_E_WORKSPACE;
+    if ((size_t)ns * ns * sizeof(float) > (size_t)g_cap(pn) * nt * 4 * pn * sizeof(float)) return LITHO_E_WORKSPACE;
     if (((size_t)(pn + 15) / 16 * 16) * (size_t)(j1 - j0) * sizeof(float2) > w.t_bytes) return LITHO_E_WORKSPACE;
     float* scaled = w.slab;                                      // the slab region is free here
     hipLaunchKernelGGL(k_twiddle_table, dim3((N + 255) / 256), dim3(256), 0, st, w.twtab, N);

@@ -116,7 +116,7 @@ int litho_abbe_last_plan(int64_t fields_host[8]);
  * and y-pass launch with HIP events recorded on `stream` (at most 4096 launches per call)
  * and waits for the last one before returning.  fields: [0]=x-pass total ms, [1]=x-pass
  * launches, [2]=source points those launches covered, [3..5]=the same for the y-pass,
- * [6]=1 when the y-pass ran the wave-per-line kernel (k_ypass_w64) instead of k_ypass_acc. */
+ * [6]=1 when the y-pass ran the wave-per-line kernel (k_ypass_wave) instead of k_ypass_acc. */
 int litho_abbe_set_profiling(int on);
 int litho_abbe_last_profile(double fields_host[8]);
 

@@ -145,4 +145,4 @@ def last_profile():
     lib().litho_abbe_last_profile(arr)
     return {"xpass_ms": arr[0], "xpass_launches": int(arr[1]), "xpass_points": int(arr[2]),
             "ypass_ms": arr[3], "ypass_launches": int(arr[4]), "ypass_points": int(arr[5]),
-            "ypass_kernel": "k_ypass_w64" if arr[6] else "k_ypass_acc"}
+            "ypass_kernel": "k_ypass_wave" if arr[6] else "k_ypass_acc"}

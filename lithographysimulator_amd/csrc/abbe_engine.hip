@@ -293,11 +293,14 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     // number of full-occupancy rounds (256 CUs x workgroups per CU), so no round runs part-empty.
     const int l2n = ilog2(N);
     const int lines_per_wg = (N / 16 >= 64) ? 1 : 64 / (N / 16);
-    const int tile_blocks = (g.nt + lines_per_wg - 1) / lines_per_wg;
     // (the wave-per-line y-pass used at 2048^2 keeps 2 workgroups per CU resident)
-    const bool w64_ok = (N == 4096 && pn == 2048) || (N == 8192 && pn == 4096 && env_int("LITHO_ABBE_W64_8192", 0));
+    // wave-per-line y-pass (k_ypass_wave): N = 2 pn with pn = 512, 1024, 2048; pn = 4096 is opt-in (slower there)
+    const bool w64_ok = (pn * 2 == N) && (N == 1024 || N == 2048 || N == 4096 ||
+                                          (N == 8192 && env_int("LITHO_ABBE_W64_8192", 0)));
     const bool w64_shape = w64_ok && env_int("LITHO_ABBE_W64", 1);
-    const int resident = 256 * (w64_shape ? (N == 4096 ? 2 : 1) : l2n <= 12 ? 3 : (l2n == 13 ? 2 : 1));
+    const int wave_tiles = (N == 1024) ? 2 : 1;                       // T tiles per wave-kernel workgroup
+    const int tile_blocks = w64_shape ? (g.nt + wave_tiles - 1) / wave_tiles : (g.nt + lines_per_wg - 1) / lines_per_wg;
+    const int resident = 256 * (w64_shape ? (N <= 2048 ? 4 : (N == 4096 ? 2 : 1)) : l2n <= 12 ? 3 : (l2n == 13 ? 2 : 1));
     int a_ = tile_blocks, b_ = resident;
     while (b_) { const int t_ = a_ % b_; a_ = b_; b_ = t_; }
     int G = resident / a_;

@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void k_xpass_w64(
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float* lds = smem + wv * Wave4096::LDS_FLOATS;
     Wave4096::LaneTwiddles tw;
-    Wave4096::load_lane_twiddles(tw, twtab, lane);
+    Wave4096::load_lane_twiddles(tw, twtab, lane, 1);
 
     const int ngroups = (g.rows + 3) >> 2;
     const int items = ngroups * nb;
@@ -462,70 +462,89 @@ __global__ __launch_bounds__(256, 2) void k_xpass_w64(
             constexpr int i = decltype(i_)::value;
             constexpr int k2 = i < 16 ? i : 32 + i;
             constexpr int kk = i < 16 ? i + 16 : i - 16;         // (q - lane) / 64
-            buf_store_c64(rT, vbase + kk * kstride, x[br6(k2)]);
+            buf_store_c64(rT, vbase + kk * kstride, x[Wave4096::brev(k2)]);
         });
     }
 }
 
 // ----------------------------------------------------------------------------------
-// y-pass, wave-per-line variant for N = 4096 * D (D = 1, 2), pn = N/2, pupil inside the unit disk.
-// D = 1: each of the 4 waves of a workgroup owns one column of the 4-column tile and transforms it on
-// its own (wave_fft.hpp): no workgroup barriers, half the LDS traffic of the radix-16 engine.
-// D = 2: decimation in frequency, out[2v + p] = sum_n' ([x[n'] + (-1)^p x[n' + 4096]] w_N^(n' p)) w_4096^(n' v):
-// two independent 4096-point sub-transforms (even / odd bins) per column, one wave each -- the pruned
-// input makes the first butterfly trivial (at most one of x[n'], x[n'+4096] is non-zero), and the two
-// waves never exchange data.  The workgroup is then 8 waves (4 columns x 2 residues), so that every consumer
-// of a T tile sits on one CU.
+// y-pass, wave-per-line variant (wave_fft.hpp) for N = S*S*D, pn = N/2, pupil inside the unit disk:
+//   N = 1024: S = 32, D = 1     N = 2048: S = 32, D = 2     N = 4096: S = 64, D = 1     N = 8192: S = 64, D = 2
+// A "unit" is one S*S-point sub-transform, computed by S lanes on their own: no workgroup barriers, half
+// the LDS traffic of the radix-16 engine.  D = 1: one unit per column.  D = 2: decimation in frequency,
+//   out[2v + p] = sum_n' ([x[n'] + (-1)^p x[n' + N/2]] w_N^(n' p)) w_{N/2}^(n' v),
+// i.e. two independent sub-transforms (even / odd bins) per column; the pruned input makes the first
+// butterfly trivial (at most one of x[n'], x[n'+N/2] is non-zero) and the two units never exchange data.
+// Every consumer of a 4-column T tile sits in the same workgroup.
 // ----------------------------------------------------------------------------------
 template <int LOG2N>
-__global__ __launch_bounds__(256 << (LOG2N - 12), 2) void k_ypass_w64(
+struct WaveShape {
+    static_assert(LOG2N >= 10 && LOG2N <= 13, "wave-per-line y-pass: N = 1024 .. 8192");
+    static constexpr int LS = LOG2N / 2;                     // 5, 5, 6, 6
+    static constexpr int D = 1 << (LOG2N - 2 * LS);          // 1, 2, 1, 2
+    using W = WaveSq<LS>;
+    static constexpr int S = W::S;
+    static constexpr int THREADS = (LS == 6 && D == 2) ? 512 : 256;
+    static constexpr int UNITS = THREADS / S;                // sub-transforms per workgroup
+    static constexpr int COLS = UNITS / D;                   // columns per workgroup (4 or 8)
+    static constexpr int TILES = COLS / 4;                   // T tiles per workgroup
+    static constexpr int JLIVE = S * D / 8;                  // live slots: j in [0, JLIVE] and [S - JLIVE, S)
+    static constexpr size_t LDS_BYTES = (size_t)(THREADS / 64) * W::LDS_FLOATS * sizeof(float);
+#ifndef LITHO_WAVE32_MINWAVES
+#define LITHO_WAVE32_MINWAVES 4
+#endif
+    static constexpr int MINWAVES = LS == 5 ? LITHO_WAVE32_MINWAVES : 2;   // S = 32 needs few registers: 4 workgroups per CU
+};
+
+template <int LOG2N>
+__global__ __launch_bounds__(WaveShape<LOG2N>::THREADS, WaveShape<LOG2N>::MINWAVES) void k_ypass_wave(
     const float2* __restrict__ Tbuf, float* __restrict__ slab, const float2* __restrict__ twtab,
     PassGeom g, int nb, int G)
 {
-    static_assert(LOG2N == 12 || LOG2N == 13, "wave-per-line y-pass: N = 4096 or 8192");
-    constexpr int D = 1 << (LOG2N - 12);
-    constexpr int N = 1 << LOG2N;
-    constexpr int JLIVE = 8 * D;                       // live slots: j in [0, JLIVE] and [64 - JLIVE, 64)
+    using WS = WaveShape<LOG2N>;
+    using W = typename WS::W;
+    constexpr int S = WS::S, D = WS::D, JLIVE = WS::JLIVE, N = 1 << LOG2N;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float* lds = smem + wv * Wave4096::LDS_FLOATS;
-    Wave4096::LaneTwiddles tw;
-    // the sub-transform's own twiddles w_4096^(lane m) are every D-th entry of the w_N table
-    static_for<0, 8>([&](auto i_) {
-        constexpr int i = decltype(i_)::value;
-        tw.row[i] = twtab[D * lane * i];
-        tw.row[8 + i] = twtab[D * lane * 8 * i];
-    });
-    const int p = wv % D;                               // which residue of the output bins this wave makes
-    const int col = wv / D;                             // column inside the 4-column tile
-    const float2 tl = twtab[lane * p];                  // w_N^(lane p)  (1 for p = 0)
+    const int l = lane & (S - 1);                            // lane inside its unit
+    const int unit = wv * W::LINES + (lane >> WS::LS);
+    const int p = unit % D;                                  // residue of the output bins this unit makes
+    const int colg = unit / D;                               // column inside the workgroup's column group
+    float* lds = smem + wv * W::LDS_FLOATS;
+    typename W::LaneTwiddles tw;
+    W::load_lane_twiddles(tw, twtab, l, D);                  // w_{S*S}^e is entry D*e of the w_N table
+    const float2 tl = twtab[l * p];                          // w_N^(l p)  (1 for p = 0)
 
-    const int tile = blockIdx.x, grp = blockIdx.y;
-    float acc[32];
-    static_for<0, 32>([&](auto i) { acc[i] = 0.f; });
+    // The tile index is wave-uniform (a wave's units cover at most one tile); readfirstlane makes that
+    // provable, otherwise every buffer access through the tile's descriptor becomes a waterfall loop.
+    const int tile = blockIdx.x * WS::TILES + (WS::TILES > 1 ? __builtin_amdgcn_readfirstlane(colg >> 2) : 0);
+    const int col = colg & 3, grp = blockIdx.y;
+    const bool active = tile < g.nt;
+    float acc[S / 2];
+    static_for<0, S / 2>([&](auto i) { acc[i] = 0.f; });
 
-    // Live input slots j (sub-transform sample n' = lane + 64 j): k = n' for j <= JLIVE, k = n' - 4096 (i.e.
-    // sample n' + N - 4096 of the full line) for j >= 64 - JLIVE; T row a = k - ky0.  The descriptor is
-    // windowed on this tile's rows ([tile][row][4] layout, 32 B per row): the range check is the validity test.
-    const unsigned tile_bytes = (unsigned)g.rows * 32u;
-    const unsigned vb = (unsigned)(lane - g.ky0) * 32u + (unsigned)col * 8u;
-    auto slot_off = [&](int j) { return vb + (unsigned)(j <= JLIVE ? 2048 * j : 2048 * j - 131072); };
+    // Live input slots j (sub-transform sample n' = l + S j): k = n' for j <= JLIVE, k = n' - S*S for the upper
+    // ones (sample n' + N - S*S of the full line); T row a = k - ky0.  The descriptor is windowed on this tile's
+    // rows ([tile][row][4] layout, 32 B per row): the range check is the validity test.
+    const unsigned tile_bytes = active ? (unsigned)g.rows * 32u : 0u;
+    const unsigned vb = (unsigned)(l - g.ky0) * 32u + (unsigned)col * 8u;
+    auto slot_off = [&](int j) { return vb + (unsigned)(j <= JLIVE ? 32 * S * j : 32 * S * j - 32 * S * S); };
 
     for (int s = grp; s < nb; s += G) {
         const __amdgpu_buffer_rsrc_t rT =
-            make_rsrc(Tbuf + (size_t)s * g.t_point + (size_t)tile * g.rows * 4, tile_bytes);
-        float2 x[64];
-        static_for<0, 64>([&](auto j_) {
+            make_rsrc(Tbuf + (size_t)s * g.t_point + (size_t)(active ? tile : 0) * g.rows * 4, tile_bytes);
+        float2 x[S];
+        static_for<0, S>([&](auto j_) {
             constexpr int j = decltype(j_)::value;
-            if constexpr (j <= JLIVE || j >= 64 - JLIVE) {
+            if constexpr (j <= JLIVE || j >= S - JLIVE) {
                 float2 v = buf_load_c64(rT, slot_off(j));
                 if constexpr (D > 1) {
-                    // w_N^(n' p) = w_N^(lane p) * w_N^(64 j p), and (-1)^p for the upper half (q = 1)
+                    // w_N^(n' p) = w_N^(l p) * w_N^(S j p), and (-1)^p for the upper half (q = 1)
                     if (p) {
-                        constexpr int e = (64 * j) % N;                       // exponent of the constant factor
+                        constexpr int e = (S * j) % N;
                         constexpr double ang = 6.283185307179586476925 * e / N;
-                        constexpr float sgn = (j >= 64 - JLIVE) ? -1.f : 1.f;
+                        constexpr float sgn = (j >= S - JLIVE) ? -1.f : 1.f;
                         const float2 cj = make_float2(sgn * (float)__builtin_cos(ang), sgn * (float)__builtin_sin(ang));
                         v = cmul(cmul(v, cj), tl);
                     }
@@ -535,24 +554,26 @@ __global__ __launch_bounds__(256 << (LOG2N - 12), 2) void k_ypass_w64(
                 x[j] = make_float2(0.f, 0.f);
             }
         });
-        Wave4096::run(x, tw, lds, lane);
-        // kept bins: v in [-1024, 1024)  ->  k2 in 0..15 and 48..63
-        static_for<0, 32>([&](auto i_) {
+        W::run(x, tw, lds, lane);
+        // kept bins of the sub-transform: v in [-S*S/4, S*S/4)  ->  k2 in [0, S/4) and [3S/4, S)
+        static_for<0, S / 2>([&](auto i_) {
             constexpr int i = decltype(i_)::value;
-            constexpr int k2 = i < 16 ? i : 32 + i;
-            const float2 v = x[br6(k2)];
+            constexpr int k2 = i < S / 4 ? i : S / 2 + i;
+            const float2 v = x[W::brev(k2)];
             acc[i] = fmaf(v.x, v.x, fmaf(v.y, v.y, acc[i]));
         });
     }
 
+    if (!active) return;
     const int qx = tile * 4 + col;
+    if (qx >= g.pn) return;
     float* srow = slab + ((size_t)grp * g.nt * 4 + qx) * g.pn;
-    static_for<0, 32>([&](auto i_) {
+    static_for<0, S / 2>([&](auto i_) {
         constexpr int i = decltype(i_)::value;
-        constexpr int k2 = i < 16 ? i : 32 + i;
-        const int n = lane + 64 * k2;
-        const int v = n < 2048 ? n : n - 4096;          // bin of the sub-transform
-        srow[D * v + p + g.c] += acc[i];                // bin u = D v + p of the full line
+        constexpr int k2 = i < S / 4 ? i : S / 2 + i;
+        const int n = l + S * k2;
+        const int v = n < S * S / 2 ? n : n - S * S;        // bin of the sub-transform
+        srow[D * v + p + g.c] += acc[i];                    // bin u = D v + p of the full line
     });
 }
 
@@ -606,7 +627,7 @@ struct SizeOps {
                             int G, hipStream_t st);
     hipError_t (*ypass_field)(int sign, const float2* T, float2* field, const float2* tw, const PassGeom& g,
                               hipStream_t st);
-    // wave-per-line passes (N = 4096, pn = 2048, pruned only); hipErrorNotSupported for other sizes
+    // wave-per-line passes (y: N = 1024..8192 with pn = N/2, pruned only; x: N = 4096); hipErrorNotSupported otherwise
     hipError_t (*xpass_w64)(const float2* P, const float2* M, const int* shifts, float2* T, const float2* tw,
                             const PassGeom& g, int nb, hipStream_t st);
     hipError_t (*ypass_w64)(const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb, int G,
@@ -707,13 +728,13 @@ struct SizeImpl {
     static hipError_t ypass_w64(const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb, int G,
                                 hipStream_t st)
     {
-        if constexpr (LOG2N == 12 || LOG2N == 13) {
-            constexpr int D = 1 << (LOG2N - 12);
-            constexpr size_t lds = 4 * D * Wave4096::LDS_FLOATS * sizeof(float);
-            auto kern = k_ypass_w64<LOG2N>;
-            hipError_t e = set_lds(kern, lds);
+        if constexpr (LOG2N >= 10 && LOG2N <= 13) {
+            using WS = WaveShape<LOG2N>;
+            auto kern = k_ypass_wave<LOG2N>;
+            hipError_t e = set_lds(kern, WS::LDS_BYTES);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, dim3(g.nt, G), dim3(256 * D), lds, st, T, slab, tw, g, nb, G);
+            hipLaunchKernelGGL(kern, dim3((g.nt + WS::TILES - 1) / WS::TILES, G), dim3(WS::THREADS), WS::LDS_BYTES, st, T,
+                               slab, tw, g, nb, G);
             return hipGetLastError();
         } else {
             return hipErrorNotSupported;

@@ -1,17 +1,18 @@
-// wave_fft.hpp -- length-4096 transform computed by ONE wavefront (64 lanes x 64 points).
+// wave_fft.hpp -- S*S-point transforms computed inside ONE wavefront, S = 64 (one 4096-point line
+// per wave) or S = 32 (two 1024-point lines per wave, one per half-wave).
 //
-//   X[m + 64 k2] = sum_l w64^(l k2) [ w4096^(l m) sum_j x[l + 64 j] w64^(j m) ]
+//   X[m + S k2] = sum_l wS^(l k2) [ w_{S*S}^(l m) sum_j x[l + S j] wS^(j m) ]
 //
-// Lane l holds x[l + 64 j] in register slot j.  Pass A is a 64-point DFT over the slots, then
-// the lane twiddle w4096^(l m), then a 64 x 64 transpose THROUGH LDS THAT ONLY THIS WAVE
-// TOUCHES (no workgroup barrier: a wave's LDS operations complete in order), then pass B, a
-// second 64-point DFT over the slots.  Lane m ends with X[m + 64 k2] in slot k2: the same
-// "lane + 64 * slot" ownership as on input.  Compared with the 256-thread radix-16 engine this
-// halves the LDS traffic and removes every s_barrier, at ~8 % more VALU work.
+// Lane l of a line holds x[l + S j] in register slot j.  Pass A is an S-point DFT over the slots,
+// then the lane twiddle w_{S*S}^(l m), then an S x S transpose THROUGH LDS THAT ONLY THIS WAVE TOUCHES
+// (no workgroup barrier: a wave's LDS operations complete in order), then pass B, a second S-point
+// DFT over the slots.  Lane m ends with X[m + S k2] in slot k2: the same "lane + S * slot"
+// ownership as on input.  Compared with the workgroup-wide radix-16 engine this halves the LDS
+// traffic and removes every s_barrier, at ~8 % more VALU work.
 //
-// The 64-point DFTs are in-place radix-2 decimation-in-frequency networks: natural order in,
-// BIT-REVERSED slot order out (slot br6(k) holds bin k); all indices are compile-time, so
-// zero inputs fold away and unused outputs are dead code.
+// The S-point DFTs are in-place radix-2 decimation-in-frequency networks: natural order in,
+// BIT-REVERSED slot order out (slot brev(k) holds bin k); all indices are compile-time, so zero
+// inputs fold away and unused outputs are dead code.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -29,11 +30,6 @@ static constexpr double W64C[33] = {
     -0.70710678118654746, -0.77301045336273699, -0.83146961230254535, -0.88192126434835494,
     -0.92387953251128674, -0.95694033573220882, -0.98078528040323043, -0.99518472667219682,
     -1};
-
-__host__ __device__ constexpr int br6(int v)
-{
-    return ((v & 1) << 5) | ((v & 2) << 3) | ((v & 4) << 1) | ((v & 8) >> 1) | ((v & 16) >> 3) | ((v & 32) >> 5);
-}
 
 // v * exp(+2 pi i M / 64), 0 <= M < 32
 template <int M>
@@ -56,74 +52,88 @@ __device__ __forceinline__ float2 mul_root64(float2 v)
     }
 }
 
-// In-place 64-point DIF: x[br6(k)] <- sum_j x[j] exp(+2 pi i j k / 64)
-__device__ __forceinline__ void dft64_dif(float2 (&x)[64])
-{
-    static_for<0, 6>([&](auto s_) {
-        constexpr int s = decltype(s_)::value;
-        constexpr int half = 32 >> s;                 // butterfly span
-        constexpr int stride = 1 << s;                // twiddle step in 64ths
-        static_for<0, 32>([&](auto b_) {
-            constexpr int b = decltype(b_)::value;
-            constexpr int grp = b / half, i = b % half;
-            constexpr int lo = grp * 2 * half + i, hi = lo + half;
-            const float2 a = x[lo], c = x[hi];
-            x[lo] = cadd(a, c);
-            x[hi] = mul_root64<(i * stride) % 32>(csub(a, c));
-        });
-    });
-}
+template <int LS>
+struct WaveSq {
+    static_assert(LS == 5 || LS == 6, "S = 32 or 64");
+    static constexpr int S = 1 << LS;                 // lanes per line = slots per lane
+    static constexpr int LINES = 64 / S;              // lines per wave
+    static constexpr int LDS_FLOATS = 64 * (S + 1);   // LINES padded S x S fp32 matrices per wave
+    static constexpr int NTW = 8 + S / 8;             // lane twiddle factors
 
-struct Wave4096 {
-    static constexpr int LDS_FLOATS = 64 * 65;       // one padded 64 x 64 fp32 matrix per wave (16.6 KB)
-
-    // Lane twiddles w4096^(lane*m), m = 8a + b, factored as w8[a]*w1[b]: 16 factors per lane, in registers
-    // (an LDS-resident table was measured slower: 9.15 vs 8.06 us/point).
-    struct LaneTwiddles {
-        float2 row[16];         // [0..7] = w4096^(l b), [8..15] = w4096^(8 l a)
-    };
-    __device__ static __forceinline__ void load_lane_twiddles(LaneTwiddles& t, const float2* __restrict__ table, int lane)
+    __host__ __device__ static constexpr int brev(int v)
     {
-        static_for<0, 8>([&](auto i_) {
-            constexpr int i = decltype(i_)::value;
-            t.row[i] = table[lane * i];
-            t.row[8 + i] = table[lane * 8 * i];
+        int r = 0;
+        for (int b = 0; b < LS; ++b) r |= ((v >> b) & 1) << (LS - 1 - b);
+        return r;
+    }
+
+    // In-place S-point DIF: x[brev(k)] <- sum_j x[j] exp(+2 pi i j k / S)
+    __device__ static __forceinline__ void dft_dif(float2 (&x)[S])
+    {
+        static_for<0, LS>([&](auto s_) {
+            constexpr int s = decltype(s_)::value;
+            constexpr int half = (S / 2) >> s;            // butterfly span
+            constexpr int stride = (64 / S) << s;         // twiddle step in 64ths
+            static_for<0, S / 2>([&](auto b_) {
+                constexpr int b = decltype(b_)::value;
+                constexpr int grp = b / half, i = b % half;
+                constexpr int lo = grp * 2 * half + i, hi = lo + half;
+                const float2 a = x[lo], c = x[hi];
+                x[lo] = cadd(a, c);
+                x[hi] = mul_root64<(i * stride) % 32>(csub(a, c));
+            });
         });
     }
 
-    // x: slot j = sample lane + 64 j (natural).  On return slot br6(k2) = bin lane + 64 k2.
-    __device__ static __forceinline__ void run(float2 (&x)[64], const LaneTwiddles& tw, float* lds, int lane)
+    // Lane twiddles w_{S*S}^(l*m), m = 8a + b, factored as w8[a]*w1[b], in registers (an LDS-resident table
+    // was measured slower: 9.15 vs 8.06 us/point at 2048^2).
+    struct LaneTwiddles {
+        float2 row[NTW];        // [0..7] = w^(l b), [8..] = w^(8 l a)
+    };
+    // table[n] = exp(2 pi i n / Ntab) with Ntab = S*S*step, so entry step*e is w_{S*S}^e.  l = lane within its line.
+    __device__ static __forceinline__ void load_lane_twiddles(LaneTwiddles& t, const float2* __restrict__ table, int l, int step)
     {
-        dft64_dif(x);                                  // slot br6(m) = y[m]
-        // lane twiddle w4096^(lane*m), m = 8 a + b
-        static_for<0, 64>([&](auto m_) {
+        static_for<0, 8>([&](auto i_) { constexpr int i = decltype(i_)::value; t.row[i] = table[step * l * i]; });
+        static_for<0, S / 8>([&](auto i_) { constexpr int i = decltype(i_)::value; t.row[8 + i] = table[step * l * 8 * i]; });
+    }
+
+    // x: slot j = sample l + S j (natural).  On return slot brev(k2) = bin l + S k2.
+    // lds: this wave's LDS_FLOATS floats; lane = 0..63.
+    __device__ static __forceinline__ void run(float2 (&x)[S], const LaneTwiddles& tw, float* lds, int lane)
+    {
+        const int l = lane & (S - 1), line = lane >> LS;
+        dft_dif(x);                                    // slot brev(m) = y[m]
+        static_for<0, S>([&](auto m_) {
             constexpr int m = decltype(m_)::value;
-            constexpr int a = m >> 3, b = m & 7, sl = br6(m);
+            constexpr int a = m >> 3, b = m & 7, sl = brev(m);
             if constexpr (b != 0) x[sl] = cmul(x[sl], tw.row[b]);
             if constexpr (a != 0) x[sl] = cmul(x[sl], tw.row[8 + a]);
         });
-        // 64 x 64 transpose, real parts then imaginary parts, through this wave's private matrix:
-        // element (row = writer lane, col = m) ; reader lane m takes column m.
-        float* const wr = lds + lane * 65;
-        float* const rd = lds + lane;
-        static_for<0, 64>([&](auto m_) { constexpr int m = decltype(m_)::value; wr[m] = x[br6(m)].x; });
+        // S x S transpose, real parts then imaginary parts, through this line's private matrix:
+        // element (row = writer lane, col = m); reader lane m takes column m.
+        float* const mat = lds + line * (S * (S + 1));
+        float* const wr = mat + l * (S + 1);
+        float* const rd = mat + l;
+        static_for<0, S>([&](auto m_) { constexpr int m = decltype(m_)::value; wr[m] = x[brev(m)].x; });
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        float re[64];
-        static_for<0, 64>([&](auto l_) { constexpr int l = decltype(l_)::value; re[l] = rd[l * 65]; });
+        float re[S];
+        static_for<0, S>([&](auto r_) { constexpr int r = decltype(r_)::value; re[r] = rd[r * (S + 1)]; });
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        static_for<0, 64>([&](auto m_) { constexpr int m = decltype(m_)::value; wr[m] = x[br6(m)].y; });
+        static_for<0, S>([&](auto m_) { constexpr int m = decltype(m_)::value; wr[m] = x[brev(m)].y; });
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        static_for<0, 64>([&](auto l_) {
-            constexpr int l = decltype(l_)::value;
-            x[l] = make_float2(re[l], rd[l * 65]);
+        static_for<0, S>([&](auto r_) {
+            constexpr int r = decltype(r_)::value;
+            x[r] = make_float2(re[r], rd[r * (S + 1)]);
         });
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        dft64_dif(x);                                  // slot br6(k2) = X[lane + 64 k2]
+        dft_dif(x);                                    // slot brev(k2) = X[l + S k2]
     }
 };
+
+using Wave4096 = WaveSq<6>;
 
 }  // namespace litho

@@ -277,7 +277,7 @@ def _with_env(monkeypatch, L, env, fn):
 
 
 def test_wave_per_line_and_radix16_ypass_agree_2048(L, dev, monkeypatch):
-    """The default y-pass at 2048^2 is the wave-per-line kernel (k_ypass_w64); the radix-16 workgroup
+    """The default y-pass at 2048^2 is the wave-per-line kernel (k_ypass_wave); the radix-16 workgroup
     kernel (k_ypass_acc), the generic runtime-predicated kernels and the general (modular) path must all
     give the same image on the same inputs."""
     from lithographysimulator_amd import _native as nat
@@ -292,7 +292,7 @@ def test_wave_per_line_and_radix16_ypass_agree_2048(L, dev, monkeypatch):
     nat.set_profiling(True)
     try:
         ref = L.abbeIntensity(mft, pf, sel, N).cpu()
-        assert nat.last_profile()["ypass_kernel"] == "k_ypass_w64" and nat.last_plan()["variant"] == 1
+        assert nat.last_profile()["ypass_kernel"] == "k_ypass_wave" and nat.last_plan()["variant"] == 1
         r16 = _with_env(monkeypatch, L, {"LITHO_ABBE_W64": "0"}, lambda: L.abbeIntensity(mft, pf, sel, N).cpu())
         assert nat.last_profile()["ypass_kernel"] == "k_ypass_acc"
     finally:

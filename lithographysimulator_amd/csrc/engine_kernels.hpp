@@ -401,6 +401,8 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
 // take the 4 rows, i.e. exactly the rows that share each 128-byte line of T, so every line is
 // completed inside one CU.  Each workgroup walks a contiguous range of items (row-group major), so
 // the grid is sized to the machine and the pupil row is re-read only when the row group changes.
+// MEASURED SLOWER than the radix-16 x-pass (10.9 vs 6.5 us/point at 2048^2: 32 scattered 8-byte stores per
+// lane), so it is opt-in (LITHO_ABBE_W64X=1) and kept only as a parity-tested alternative.
 // ----------------------------------------------------------------------------------
 template <int LOG2N>
 __global__ __launch_bounds__(256, 2) void k_xpass_w64(
@@ -409,7 +411,8 @@ __global__ __launch_bounds__(256, 2) void k_xpass_w64(
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: descriptors built from it stay scalar
     float* lds = smem + wv * Wave4096::LDS_FLOATS;
     Wave4096::LaneTwiddles tw;
     Wave4096::load_lane_twiddles(tw, twtab, lane, 1);

@@ -6,7 +6,7 @@
 // matter (pn a power of two, pupil support inside the unit-radius disk, N/pn = 1, 2 or 4) the
 // slot sets are compile-time template parameters: empty slots are literal zeros that the
 // compiler folds through the first butterfly stage (file is built with -fno-signed-zeros),
-// discarded outputs are dead code, and the prefetch buffers only have the live slots.
+// discarded outputs are dead code, and the per-slot arrays only have the live slots.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -51,13 +51,8 @@ struct Launch {
     // (measured at 4096^2: y-pass 96 -> 58 us/point).  N = 16384 needs 147 KB LDS: one.
     static constexpr int WG_PER_CU = LOG2N <= 12 ? LITHO_WG_PER_CU : (LOG2N == 13 ? 2 : 1);
     static constexpr int WAVES = (THREADS / 256 > 0 ? THREADS / 256 : 1) * WG_PER_CU;
-    // Software prefetch of the next line's inputs: measured SLOWER on gfx950 (the extra live registers
-    // spill: 35.9 vs 28.7 us/point at 2048^2), so it is off unless a build asks for it.
-#ifdef LITHO_PREFETCH
-    static constexpr bool PREFETCH = true;
-#else
-    static constexpr bool PREFETCH = false;
-#endif
+    // (Software prefetch of the next line's inputs was measured SLOWER on gfx950 -- the extra live
+    // registers spill, 35.9 vs 28.7 us/point at 2048^2 -- and is not implemented.)
 };
 
 // Slot sets.  RL = log2(N/pn) for power-of-two pn (else -1).  PRUNED: the input window lies in
@@ -178,18 +173,15 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
         });
     };
 
-    if (s_begin < s_end) load_window(s_begin);
     int flip = 0;
     for (int s = s_begin; s < s_end; ++s) {
+        load_window(s);
         float2 x[16];
         static_for<0, 16>([&](auto e_) {
             constexpr int e = decltype(e_)::value;
             if constexpr ((IN >> e) & 1u) x[e] = cmul(pv[e], mv[e]);
             else x[e] = make_float2(0.f, 0.f);
         });
-        if constexpr (PRUNED && LC::PREFETCH) {
-            if (s + 1 < s_end) load_window(s + 1);            // prefetch: in flight during the transform
-        }
         F::template run<LC::NBUF>(x, tw, lds, lt, flip);
         const __amdgpu_buffer_rsrc_t rT =
             make_rsrc(Tbuf + (size_t)s * g.t_point, (size_t)g.t_point * sizeof(float2));
@@ -203,9 +195,6 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
             if constexpr ((OUT >> m) & 1u) buf_store_c64(rT, toff[m], x[m]);
 #endif
         });
-        if constexpr (!(PRUNED && LC::PREFETCH)) {
-            if (s + 1 < s_end) load_window(s + 1);
-        }
     }
 }
 
@@ -352,23 +341,16 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
     };
 
     int flip = 0;
-    if constexpr (PRUNED && LC::PREFETCH) {
-        if (grp < nb) load_column(grp, 0);
-    }
     for (int s = grp; s < nb; s += G) {
         static_for<0, 4>([&](auto c_) {
             constexpr int cidx = decltype(c_)::value;
-            if constexpr (!(PRUNED && LC::PREFETCH)) load_column(s, cidx);
+            load_column(s, cidx);
             float2 x[16];
             static_for<0, 16>([&](auto e_) {
                 constexpr int e = decltype(e_)::value;
                 if constexpr ((IN >> e) & 1u) x[e] = nx[e];
                 else x[e] = make_float2(0.f, 0.f);
             });
-            if constexpr (PRUNED && LC::PREFETCH) {        // prefetch the next line while this one transforms
-                if constexpr (cidx < 3) load_column(s, cidx + 1);
-                else if (s + G < nb) load_column(s + G, 0);
-            }
             F::template run<LC::NBUF>(x, tw, lds, lt, flip);
             static_for<0, 16>([&](auto m_) {
                 constexpr int m = decltype(m_)::value;

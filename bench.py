@@ -32,6 +32,7 @@ WL, NA, PS = 193.0, 0.7, 25
 DEMO_AB = [0, 0, 0.01, 0, 100, 0.01, 0, 0.01, 0.01, 0.01]
 WORKLOADS = {
     # name: (pn, source kind, aberrations, description)
+    "cfg1": (256, "circ", None, "256x256 bernoulli mask, circular source sigma 0.5, ideal pupil (the reference's CPU-runnable case)"),
     "cfg2": (1024, "annular", [0, 0, 0, 0, 100], "1024x1024 bernoulli mask, annular 0.4-0.8, defocus-only pupil"),
     "cfg3": (2048, "quasar", DEMO_AB, "2048x2048 bernoulli mask, quasar(4,-pi/8) 0.4-0.8, 10-term Zernike pupil"),
     "cfg4": (4096, "annular", [0, 0, 0, 0, 100], "4096x4096 bernoulli mask, annular 0.4-0.8, defocus-only pupil"),
@@ -76,9 +77,12 @@ def main():
     mask = L.Mask(bernoulli_mask(pn), PS, dev)
     maskFT = mask.fraunhofer(WL, True)
     epsilon, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
-    ls = L.LightSource(0.4, 0.8, pn, NA, device=dev)
-    bitmap = ls.generateAnnular() if skind == "annular" else ls.generateQuasar(4, -math.pi / 8)
-    pupil = L.Pupil(pn, WL, NA, torch.tensor(ab, dtype=torch.float16), dev).generatePupilFunction()
+    if skind == "circ":
+        bitmap = L.LightSource(0.0, 0.5, pn, NA, device=dev).generateAnnular()
+    else:
+        ls = L.LightSource(0.4, 0.8, pn, NA, device=dev)
+        bitmap = ls.generateAnnular() if skind == "annular" else ls.generateQuasar(4, -math.pi / 8)
+    pupil = L.Pupil(pn, WL, NA, None if ab is None else torch.tensor(ab, dtype=torch.float16), dev).generatePupilFunction()
     S = int(bitmap.sum())
     torch.cuda.synchronize()
 
@@ -159,7 +163,7 @@ def main():
         # 32 threads is the fastest setting for this op chain on the GPU box's 2 x EPYC 9575F (256 hw threads:
         # 8 -> 2.1e7, 32 -> 2.6e7, 256 -> 1.6e6 pt*px/s; scripts/cpu_threads_probe.py), so that is the baseline.
         torch.set_num_threads(min(os.cpu_count() or 1, 32))
-        K = {1024: 16, 2048: 8, 4096: 4}.get(pn, 8)
+        K = {256: 64, 1024: 16, 2048: 8, 4096: 4}.get(pn, 8)
         shifts = L.sourceShifts(bitmap, pn)
         sel = shifts[(torch.arange(K, device=dev) * S) // K].cpu()
         m_cpu, p_cpu = maskFT.cpu(), pupil.cpu()

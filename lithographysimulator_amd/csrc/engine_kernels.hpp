@@ -447,7 +447,11 @@ __global__ __launch_bounds__(256, 2) void k_xpass_w64(
             constexpr int i = decltype(i_)::value;
             constexpr int k2 = i < 16 ? i : 32 + i;
             constexpr int kk = i < 16 ? i + 16 : i - 16;         // (q - lane) / 64
+#ifdef LITHO_DIAG_XNOSTORE
+            diag_keep(x[Wave4096::brev(k2)], vbase + kk * kstride);
+#else
             buf_store_c64(rT, vbase + kk * kstride, x[Wave4096::brev(k2)]);
+#endif
         });
     }
 }

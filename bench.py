@@ -73,7 +73,10 @@ def main():
     from lithographysimulator_amd import _native as nat
     from lithographysimulator_amd.synthetic import bernoulli_mask
 
+    import contextlib
     pn, skind, ab, desc = WORKLOADS[args.workload]
+    _notices = contextlib.redirect_stdout(sys.stderr)      # the object API prints reference-style notices
+    _notices.__enter__()
     mask = L.Mask(bernoulli_mask(pn), PS, dev)
     maskFT = mask.fraunhofer(WL, True)
     epsilon, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
@@ -85,6 +88,7 @@ def main():
     pupil = L.Pupil(pn, WL, NA, None if ab is None else torch.tensor(ab, dtype=torch.float16), dev).generatePupilFunction()
     S = int(bitmap.sum())
     torch.cuda.synchronize()
+    _notices.__exit__(None, None, None)
 
     def step():
         return L.abbeImage(mask, maskFT, pupil, bitmap, PS, mask.deltaK, WL, True, dev, group=group)

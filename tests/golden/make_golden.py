@@ -307,9 +307,29 @@ def g6_through_focus():
     save("g6_through_focus.npz", **out)
 
 
+def g8_large_pupils():
+    """Pupil support at the sizes where the fp16 sigma grid gets coarse (4096: exact, 8192: the step 4/8192 is
+    below fp16 resolution near 1): count, bounding box, hash of W, and a strided sample of phi."""
+    print("G8 large pupils")
+    out = {}
+    for pn in (4096, 8192):
+        for name in ("ideal", "defocus_p100"):
+            W = wavefront(pn, PUPIL_CASES[name])
+            phi = pupil_fn(pn, PUPIL_CASES[name])
+            nzmask = phi != 0
+            rows = torch.nonzero(nzmask.any(1)).flatten(); cols = torch.nonzero(nzmask.any(0)).flatten()
+            out[f"nz_{name}_{pn}"] = np.int64(nzmask.sum())
+            out[f"box_{name}_{pn}"] = np.array([int(rows[0]), int(rows[-1]), int(cols[0]), int(cols[-1])], dtype=np.int64)
+            out[f"Wsha_{name}_{pn}"] = np.frombuffer(hashlib.sha256(W.numpy().tobytes()).digest(), dtype=np.uint8)
+            out[f"phisub_{name}_{pn}"] = phi[::64, ::64].contiguous()
+            out[f"rowcount_{name}_{pn}"] = nzmask.sum(1).to(torch.int32)
+            del W, phi, nzmask
+    save("g8_large_pupils.npz", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8"]
     for g in which:
         {"g1": g1_sources, "g2": g2_pupils, "g3": g3_mask_spectra, "g4": g4_fields,
-         "g5": g5_images, "g6": g6_through_focus}[g]()
+         "g5": g5_images, "g6": g6_through_focus, "g8": g8_large_pupils}[g]()

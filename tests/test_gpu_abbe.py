@@ -320,3 +320,73 @@ def test_optin_wave_kernel_4096_agrees(L, dev, monkeypatch):
     ref = L.abbeIntensity(mft, pf, sel, N).cpu()
     w64 = _with_env(monkeypatch, L, {"LITHO_ABBE_W64_8192": "1"}, lambda: L.abbeIntensity(mft, pf, sel, N).cpu())
     assert rel_max(w64, ref) < 2e-6
+
+
+def test_stack_through_wave_kernel_2048(L, dev):
+    """A through-focus stack (planes > 1) at 2048^2 goes plane by plane through the same kernels:
+    plane p of the stacked call == the single-plane call with pupil p."""
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    pn = 2048
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    stack = L.throughFocusPupils(pn, WL, NA, f16(DEMO_AB), [-150.0, 50.0], dev)
+    sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateQuasar(4, -math.pi / 8), pn)
+    sel = sh[(torch.arange(5, device=dev) * sh.shape[0]) // 5]
+    both = L.abbeIntensity(mft, stack, sel, N).cpu()
+    assert both.shape == (2, pn, pn)
+    for k in range(2):
+        one = L.abbeIntensity(mft, stack[k], sel, N).cpu()
+        assert rel_max(both[k], one) < 1e-6
+    assert rel_max(both[0], both[1]) > 1e-3            # the planes really differ
+
+
+def test_wide_pupil_forces_generic_variant_1024(L, dev):
+    """A pupil whose support is wider than the unit disk (here: a Gaussian-apodised square of 70 % of the
+    grid) cannot use the pruned slot sets: the generic, runtime-predicated kernels must handle it."""
+    from lithographysimulator_amd import _native as nat
+    o = O()
+    pn, N = 1024, 2048
+    gen = torch.Generator().manual_seed(11)
+    yy, xx = torch.meshgrid(torch.arange(pn) - pn // 2, torch.arange(pn) - pn // 2, indexing="ij")
+    inside = (yy.abs() < 0.35 * pn) & (xx.abs() < 0.35 * pn)
+    pupil = torch.where(inside, torch.polar(torch.exp(-(xx ** 2 + yy ** 2) / (0.3 * pn) ** 2),
+                                            0.002 * (xx * yy).float() / pn), torch.zeros((), dtype=torch.complex64))
+    pupil = pupil.to(torch.complex64)
+    mft = torch.complex(torch.randn(pn, pn, generator=gen), torch.randn(pn, pn, generator=gen))
+    shifts = torch.tensor([[0, 0], [37, -52], [-90, 14]], dtype=torch.int32)
+    got = L.abbeIntensity(mft.to(dev), pupil.to(dev), shifts.to(dev), N).cpu()
+    plan = nat.last_plan()
+    assert plan["variant"] == -1 and plan["general"] == 0 and plan["box_rows"] > pn // 2 + 1
+    ref = o.abbe_raw(mft, pupil, shifts, N)
+    assert rel_max(got, ref) < TOL_IMAGE_MAX and rel_l2(got, ref) < TOL_IMAGE_L2
+
+
+def test_largest_size_8192_self_consistent(L, dev, monkeypatch):
+    """pn = 8192, N = 16384 (the largest plan: 1024-thread workgroups).  The CPU oracle would need minutes per
+    source point here, so the check is internal: box-pruned path == general (modular) path, additivity, and the
+    Parseval bound."""
+    from lithographysimulator_amd import _native as nat
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    pn = 8192
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    assert N == 16384
+    mft = mask.fraunhofer(WL, True)
+    pf = L.Pupil(pn, WL, NA, f16([0, 0, 0, 0, 100]), dev).generatePupilFunction()
+    shifts = torch.tensor([[0, 0], [611, -377]], dtype=torch.int32, device=dev)
+    ref = L.abbeIntensity(mft, pf, shifts, N)
+    # At 8192 the reference's fp16 sigma grid is coarser than its own step (4/8192 < fp16 resolution near 1), so
+    # the r <= 1 support is a little wider than pn/2 + 1 and the engine must fall back to the generic kernels.
+    plan = nat.last_plan()
+    assert plan["general"] == 0 and plan["box_rows"] >= pn // 2 + 1
+    assert plan["variant"] == (1 if plan["box_rows"] == pn // 2 + 1 else -1)
+    general = _with_env(monkeypatch, L, {"LITHO_ABBE_FORCE_GENERAL": "1"}, lambda: L.abbeIntensity(mft, pf, shifts[1:], N))
+    second = L.abbeIntensity(mft, pf, shifts[1:], N)
+    assert rel_max(general.cpu(), second.cpu()) < 5e-6
+    first = L.abbeIntensity(mft, pf, shifts[:1], N)
+    assert rel_max((first + second).cpu(), ref.cpu()) < 2e-6
+    A = pf * mft
+    assert float(first.double().sum()) <= float(N) ** 2 * float((A.abs().double() ** 2).sum()) * (1 + 1e-5)
+    img = L.postProcess(ref, eps)
+    assert img.shape == (8192, 8192)                     # SURVEY Q5 table: 8192 -> 8192

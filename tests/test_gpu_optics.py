@@ -180,3 +180,19 @@ def test_postprocess_other_epsilons(L, dev, ps):
     got = L.postProcess(-raw.to(dev), eps).cpu()            # abs() is part of the post-process
     ref = O.post_process(raw, eps)
     assert got.shape == ref.shape and rel_max(got, ref) < 1e-6
+
+
+@pytest.mark.parametrize("pn", [4096, 8192])
+def test_pupil_support_at_large_sizes(golden, L, dev, pn):
+    """pn = 8192: the reference's fp16 sigma grid is coarser than its own step, its r <= 1 support is 4099 wide
+    (golden g8); the HIP kernel's 16-lane arange recipe has to land on exactly the same pixels."""
+    g = golden("g8_large_pupils.npz")
+    for name, ab in (("ideal", None), ("defocus_p100", [0, 0, 0, 0, 100])):
+        phi = L.Pupil(pn, WL, NA, None if ab is None else f16(ab), dev).generatePupilFunction()
+        nz = phi != 0
+        assert int(nz.sum()) == int(g[f"nz_{name}_{pn}"])
+        assert np.array_equal(nz.sum(1).to(torch.int32).cpu().numpy(), g[f"rowcount_{name}_{pn}"])
+        rows = torch.nonzero(nz.any(1)).flatten(); cols = torch.nonzero(nz.any(0)).flatten()
+        assert [int(rows[0]), int(rows[-1]), int(cols[0]), int(cols[-1])] == list(g[f"box_{name}_{pn}"])
+        sub = phi[::64, ::64].cpu()
+        assert int(((sub - torch.from_numpy(g[f"phisub_{name}_{pn}"])).abs() >= TOL_PHI).sum()) <= 2

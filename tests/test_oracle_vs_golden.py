@@ -224,3 +224,20 @@ def test_through_focus_64(golden):
         pf = O.pupil_function(f16(ab), 64, NA, WL)
         final = O.abbe_image(mft, pf, bm, PS, 4 / 64, WL)
         assert rel_max(final, g["stack64_final"][k]) < TOL_IMAGE_MAX
+
+
+# ---------------------------------------------------------------- G8 (coarse fp16 grid at 8192)
+@pytest.mark.parametrize("pn", [4096, 8192])
+def test_pupil_support_at_large_sizes(golden, pn):
+    """At pn = 8192 the sigma step 4/8192 is finer than fp16 can hold near 1, so the reference's r <= 1 support
+    is 4099 wide instead of pn/2 + 1; the oracle's arange recipe must reproduce that bit for bit."""
+    import hashlib
+    g = golden("g8_large_pupils.npz")
+    W = O.wavefront_error(f16([0, 0, 0, 0, 100]), pn, NA, WL)
+    assert np.array_equal(np.frombuffer(hashlib.sha256(W.numpy().tobytes()).digest(), dtype=np.uint8),
+                          g[f"Wsha_defocus_p100_{pn}"])
+    phi = O.pupil_from_wavefront(W, pn)
+    nz = phi != 0
+    assert int(nz.sum()) == int(g[f"nz_defocus_p100_{pn}"])
+    assert np.array_equal(nz.sum(1).to(torch.int32).numpy(), g[f"rowcount_defocus_p100_{pn}"])
+    assert np.array_equal(phi[::64, ::64].numpy(), g[f"phisub_defocus_p100_{pn}"])

@@ -9,7 +9,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-functi
 # per transform (and 40-80 VGPRs).
 FFTFLAGS := -fno-signed-zeros -fno-slp-vectorize
 INST := $(patsubst $(CSRC)/%.hip,build/%.o,$(wildcard $(CSRC)/inst_*.hip))
-HDRS := $(CSRC)/fft_core.hpp $(CSRC)/engine_kernels.hpp $(CSRC)/engine_common.hpp include/litho_abbe.h
+HDRS := $(CSRC)/fft_core.hpp $(CSRC)/wave_fft.hpp $(CSRC)/engine_kernels.hpp $(CSRC)/engine_common.hpp include/litho_abbe.h
 
 all: $(OUT) oracle
 

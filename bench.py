@@ -1,66 +1,121 @@
 #!/usr/bin/env python3
 """Headline benchmark: Abbe source-points x image-pixels per second on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg1..cfg5] [--shard i/n] [--points K]
 
-One "step" = one complete abbeImage call (source-list compaction, Abbe accumulation over
-every source point of the configuration, all-reduce when N > 1, post-process) on synthetic
-inputs that are resident in HBM when the timed region starts.  Default workload = BASELINE
-config 3, the one the roofline target is quoted on: 2048x2048 bernoulli mask, quasar source
-sigma 0.4-0.8 (S = 198,108), 10-term Zernike-aberrated pupil.  With N > 1 (launched by
-torch.distributed.run, one rank per GPU) the source list is split into N contiguous shards and
-the partial intensities are summed by ONE RCCL all-reduce: total work is fixed -> "strong".
+One "step" = one complete abbeImage call (source-list compaction, Abbe accumulation over every source point --
+and every through-focus plane -- of the configuration, all-reduce when N > 1, post-process) on synthetic inputs
+that are resident in HBM when the timed region starts.  Default workload = BASELINE config 3, the one the
+roofline target is quoted on: 2048x2048 bernoulli mask, quasar source sigma 0.4-0.8 (S = 198,108), 10-term
+Zernike-aberrated pupil.  With N > 1 (one rank per GPU, RCCL) the source list is split into N contiguous shards
+and the partial intensities are summed by ONE all-reduce: total work is fixed -> "strong".
 
-Rank 0 prints one JSON line (contract in the task statement) carrying `roofline` (dominant
-kernel, HIP-event timed live) and, at N = 1, `cpu_baseline` (the oracle's torch-CPU op chain,
-i.e. a port of the reference loop, on a bounded sample of the same workload).
+Launching: under torch.distributed.run the ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the
+environment.  Started as a plain process with --gpus N > 1, this file starts the N ranks ITSELF as fresh child
+processes (before anything in the parent touches the GPU), waits for them and relays rank 0's JSON line.
+
+Rank 0 prints one JSON line (contract in the task statement) carrying
+  roofline     the dominant kernel against the bound the counters show: VALU issue.  achieved = nominal FFT flops
+               (5 N log2 N per transformed line) of one launch / its HIP-event-timed duration, peak = 157.3
+               TFLOP/s fp32 vector.  The HBM view sits beside it: `traffic` = PMC-measured memory-side bytes per
+               launch of THIS workload (profiles/traffic.json, made by scripts/pmc_traffic.sh from rocprofv3 --pmc
+               passes over this very command), `hbm.measured_frac` = traffic / time / 8 TB/s, and
+               `hbm.effective_40B` = the SURVEY 8d 40-byte model over kernel time, labelled effective because
+               most of those bytes are never moved (pupil-box pruning, on-chip accumulators, cache-resident M/P);
+  cpu_baseline (N = 1) the oracle's torch-CPU op chain, i.e. a port of the reference loop, on a bounded sample.
 """
 import argparse
 import json
 import math
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WL, NA, PS = 193.0, 0.7, 25
 DEMO_AB = [0, 0, 0.01, 0, 100, 0.01, 0, 0.01, 0.01, 0.01]
+DEFOCUS_NM = [-310 + 20 * k for k in range(32)]           # config 5
 WORKLOADS = {
-    # name: (pn, source kind, aberrations, description)
-    "cfg1": (256, "circ", None, "256x256 bernoulli mask, circular source sigma 0.5, ideal pupil (the reference's CPU-runnable case)"),
-    "cfg2": (1024, "annular", [0, 0, 0, 0, 100], "1024x1024 bernoulli mask, annular 0.4-0.8, defocus-only pupil"),
-    "cfg3": (2048, "quasar", DEMO_AB, "2048x2048 bernoulli mask, quasar(4,-pi/8) 0.4-0.8, 10-term Zernike pupil"),
-    "cfg4": (4096, "annular", [0, 0, 0, 0, 100], "4096x4096 bernoulli mask, annular 0.4-0.8, defocus-only pupil"),
+    # name: (pn, source kind, aberrations, planes, description)
+    "cfg1": (256, "circ", None, 1, "256x256 bernoulli mask, circular source sigma 0.5, ideal pupil (the reference's CPU-runnable case)"),
+    "cfg2": (1024, "annular", [0, 0, 0, 0, 100], 1, "1024x1024 bernoulli mask, annular 0.4-0.8, defocus-only pupil"),
+    "cfg3": (2048, "quasar", DEMO_AB, 1, "2048x2048 bernoulli mask, quasar(4,-pi/8) 0.4-0.8, 10-term Zernike pupil"),
+    "cfg4": (4096, "annular", [0, 0, 0, 0, 100], 1, "4096x4096 bernoulli mask, annular 0.4-0.8, defocus-only pupil"),
+    "cfg5": (2048, "quasar", DEMO_AB, 32, "2048x2048 bernoulli mask x 32-plane through-focus stack (defocus -310..310 nm), quasar(4,-pi/8) 0.4-0.8"),
 }
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_PEAK_TFLOPS = 157.3              # MI355X_MICROARCH.md: peak fp32 vector
 # Algorithmic bytes per source-point*pixel: 40 for the fused pipeline =
 # x-pass 24 (read mask window 8 + pupil window 8, write intermediate 8) + y-pass 16 (read
 # intermediate 8, read-modify-write intensity 8).
 ALGO_BYTES = {"xpass": 24.0, "ypass": 16.0}
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS))
+    ap.add_argument("--shard", default=None, metavar="i/n",
+                    help="single GPU only: process shard i of n of the source list (the per-rank work of the n-GPU run, "
+                         "without the all-reduce)")
+    ap.add_argument("--points", type=int, default=0,
+                    help="profiling aid: only the first K consecutive source points (the JSON line is then marked partial)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def spawn_ranks(args):
+    """Parent of a plain `python bench.py --gpus N`: start N fresh rank processes (this process has not touched the
+    GPU and never will), relay rank 0's stdout, exit with the worst return code.  If one rank dies the others are
+    ended (by PID) instead of waiting for a rendezvous that cannot complete."""
+    import tempfile
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    worst = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0:
+                worst = max(worst, abs(rc) or 1)
+                for q in live:
+                    q.terminate()
+    out0.seek(0)
+    sys.stdout.write(out0.read())
+    sys.stdout.flush()
+    sys.exit(worst)
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)
+
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N with N > 1 must be launched by torch.distributed.run (one rank per GPU)")
-        args.gpus = world
-    import torch.distributed as dist
+    args.gpus = world
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     group = None
@@ -74,7 +129,7 @@ def main():
     from lithographysimulator_amd.synthetic import bernoulli_mask
 
     import contextlib
-    pn, skind, ab, desc = WORKLOADS[args.workload]
+    pn, skind, ab, planes, desc = WORKLOADS[args.workload]
     _notices = contextlib.redirect_stdout(sys.stderr)      # the object API prints reference-style notices
     _notices.__enter__()
     mask = L.Mask(bernoulli_mask(pn), PS, dev)
@@ -85,13 +140,34 @@ def main():
     else:
         ls = L.LightSource(0.4, 0.8, pn, NA, device=dev)
         bitmap = ls.generateAnnular() if skind == "annular" else ls.generateQuasar(4, -math.pi / 8)
-    pupil = L.Pupil(pn, WL, NA, None if ab is None else torch.tensor(ab, dtype=torch.float16), dev).generatePupilFunction()
-    S = int(bitmap.sum())
+    if planes == 1:
+        pupil = L.Pupil(pn, WL, NA, None if ab is None else torch.tensor(ab, dtype=torch.float16), dev).generatePupilFunction()
+    else:
+        pupil = L.throughFocusPupils(pn, WL, NA, torch.tensor(ab, dtype=torch.float16), [float(d) for d in DEFOCUS_NM[:planes]], dev)
+    S_full = int(bitmap.sum())
     torch.cuda.synchronize()
     _notices.__exit__(None, None, None)
 
+    # ---- what one step processes
+    lo, hi, shard_note = 0, S_full, None
+    if args.shard:
+        if world > 1:
+            sys.exit("--shard is a single-GPU option")
+        i, n = (int(v) for v in args.shard.split("/"))
+        from lithographysimulator_amd.distributed import shard_bounds
+        lo, hi = shard_bounds(S_full, i, n)
+        shard_note = f"shard {i}/{n} of the source list (per-rank work of the {n}-GPU run, no all-reduce)"
+    if args.points > 0:
+        hi = min(hi, lo + args.points)
+        shard_note = (shard_note + "; " if shard_note else "") + f"PARTIAL: first {hi - lo} consecutive source points only"
+    S = hi - lo
+    partial = (lo, hi) != (0, S_full)
+
     def step():
-        return L.abbeImage(mask, maskFT, pupil, bitmap, PS, mask.deltaK, WL, True, dev, group=group)
+        if not partial:
+            return L.abbeImage(mask, maskFT, pupil, bitmap, PS, mask.deltaK, WL, True, dev, group=group)
+        sh = L.sourceShifts(bitmap, pn)[lo:hi]              # the three lines abbeImage runs per rank
+        return L.postProcess(L.abbeIntensity(maskFT, pupil, sh, N), epsilon)
 
     def fence():
         torch.cuda.synchronize()
@@ -112,7 +188,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
-    units = float(S) * pn * pn                                   # source-point*pixels per step, whole job
+    units = float(S) * pn * pn * planes                          # source-point*pixels per step, whole job
     value = units * args.steps / elapsed
 
     # ---- roofline leg: HIP-event time of each kernel class over one more (untimed) step of this rank's shard
@@ -122,40 +198,67 @@ def main():
     prof = nat.last_profile()
     plan = nat.last_plan()
     nat.set_profiling(False)
+    lines = {"xpass": plan["box_rows"], "ypass": pn}            # length-N lines transformed per T item
+    line_flops = 5.0 * N * math.log2(N)                          # nominal FFT flops of one length-N line
     kern = {}
     for k in ("xpass", "ypass"):
         launches = max(1, prof[f"{k}_launches"])
-        pts = prof[f"{k}_points"]
+        items = prof[f"{k}_points"]                              # T items = source points x planes
         avg_ms = prof[f"{k}_ms"] / launches
-        algo_bytes_per_launch = ALGO_BYTES[k] * pn * pn * pts / launches
-        kern[k] = {"avg_launch_ms": avg_ms, "launches": launches, "points_per_launch": pts / launches,
-                   "algorithmic_bytes_per_launch": algo_bytes_per_launch,
-                   "achieved_GBs": algo_bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
+        per_launch = items / launches
+        flops = line_flops * lines[k] * per_launch
+        algo_bytes = ALGO_BYTES[k] * pn * pn * per_launch
+        kern[k] = {"avg_launch_ms": avg_ms, "launches": launches, "items_per_launch": per_launch,
+                   "nominal_flops_per_launch": flops,
+                   "achieved_TFLOPs": flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
+                   "algorithmic_bytes_per_launch": algo_bytes,
+                   "effective_GBs": algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
                    "total_ms": prof[f"{k}_ms"]}
     dom = max(kern, key=lambda k: kern[k]["total_ms"])
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")       # PMC-derived HBM bytes per launch (rocprofv3 --pmc)
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")       # PMC-derived memory-side bytes (rocprofv3 --pmc)
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
+            entry = json.load(open(tpath)).get(args.workload, {})
+            per_item = entry.get(dom + "_bytes_per_item")
+            if per_item is not None:
+                traffic = per_item * kern[dom]["items_per_launch"]
+                traffic_src = entry.get("source")
         except Exception:
             traffic = None
     both_ms = kern["xpass"]["total_ms"] + kern["ypass"]["total_ms"]
-    roofline = {"bound": "hbm", "kernel": prof["ypass_kernel"] if dom == "ypass" else "k_xpass_abbe",
-                "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": kern[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
+    both_flops = sum(kern[k]["nominal_flops_per_launch"] * kern[k]["launches"] for k in kern)
+    eff40 = 40.0 * pn * pn * prof["ypass_points"] / (both_ms * 1e-3) / 1e9 if both_ms else 0.0
+    dom_s = kern[dom]["avg_launch_ms"] * 1e-3
+    roofline = {"bound": "valu", "kernel": prof["ypass_kernel"] if dom == "ypass" else "k_xpass_abbe",
+                "achieved": kern[dom]["achieved_TFLOPs"], "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": kern[dom]["achieved_TFLOPs"] / VALU_PEAK_TFLOPS, "traffic": traffic,
                 "avg_launch_ms": kern[dom]["avg_launch_ms"],
-                "algorithmic_bytes_per_launch": kern[dom]["algorithmic_bytes_per_launch"],
-                "pipeline_40B": {"achieved": 40.0 * pn * pn * prof["ypass_points"] / (both_ms * 1e-3) / 1e9 if both_ms else 0.0,
-                                 "frac": 40.0 * pn * pn * prof["ypass_points"] / (both_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if both_ms else 0.0,
-                                 "note": "effective: 40 B/unit model over x-pass + y-pass kernel time; real HBM bytes are lower (see traffic)"},
+                "nominal_flops_per_launch": kern[dom]["nominal_flops_per_launch"],
+                "note": "measured limiter is fp32 VALU issue (PMC: profiles/); achieved = nominal 5*N*log2(N) flops per "
+                        "transformed line (pruned transforms execute fewer) / HIP-event launch time; traffic = PMC "
+                        "memory-side bytes per launch of this workload",
+                "pipeline": {"achieved": both_flops / (both_ms * 1e-3) / 1e12 if both_ms else 0.0,
+                             "frac": both_flops / (both_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS if both_ms else 0.0,
+                             "note": "x-pass + y-pass nominal flops over their summed kernel time"},
+                "hbm": {"peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "measured": traffic / dom_s / 1e9 if traffic and dom_s > 0 else None,
+                        "measured_frac": traffic / dom_s / 1e9 / HBM_PEAK_GBS if traffic and dom_s > 0 else None,
+                        "traffic_source": traffic_src,
+                        "algorithmic_bytes_per_launch": kern[dom]["algorithmic_bytes_per_launch"],
+                        "effective_kernel": kern[dom]["effective_GBs"],
+                        "effective_40B": eff40, "effective_40B_over_peak": eff40 / HBM_PEAK_GBS,
+                        "note": "effective_* divide the SURVEY 8d byte MODEL (16 B/unit y-pass, 24 B/unit x-pass, 40 B/unit "
+                                "pipeline) by kernel time; they exceed what HBM could stream because most of those "
+                                "bytes are never moved -- not a roofline fraction"},
                 "kernels": kern}
 
     out = {"metric": "Abbe source-points x image-pixels per second", "value": value, "unit": "source-pt*px/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic",
-           "config": {"workload": f"BASELINE {args.workload}: {desc}", "pn": pn, "fft_n": N, "source_points": S,
+           "config": {"workload": f"BASELINE {args.workload}: {desc}" + (f" [{shard_note}]" if shard_note else ""),
+                      "pn": pn, "fft_n": N, "source_points": S, "source_points_full": S_full, "planes": planes,
                       "points_per_rank": math.ceil(S / world), "pixel_size": PS, "wavelength": WL, "NA": NA,
                       "parallelism": f"source-point shards x{world}, one all-reduce" if world > 1 else "single GPU",
                       "plan": plan, "image_shape": list(image.shape)},
@@ -169,8 +272,9 @@ def main():
         torch.set_num_threads(min(os.cpu_count() or 1, 32))
         K = {256: 64, 1024: 16, 2048: 8, 4096: 4}.get(pn, 8)
         shifts = L.sourceShifts(bitmap, pn)
-        sel = shifts[(torch.arange(K, device=dev) * S) // K].cpu()
-        m_cpu, p_cpu = maskFT.cpu(), pupil.cpu()
+        sel = shifts[(torch.arange(K, device=dev) * S_full) // K].cpu()
+        p_one = pupil if planes == 1 else pupil[planes // 2]
+        m_cpu, p_cpu = maskFT.cpu(), p_one.cpu()
         O.abbe_raw(m_cpu, p_cpu, sel[:1], N)                        # warm-up
         times = []
         for _ in range(3):
@@ -178,17 +282,18 @@ def main():
             ref_raw = O.abbe_raw(m_cpu, p_cpu, sel, N)
             times.append(time.perf_counter() - c0)
         tmed = statistics.median(times)
-        gpu_raw = L.abbeIntensity(maskFT, pupil, sel.to(dev), N).cpu()
+        gpu_raw = L.abbeIntensity(maskFT, p_one, sel.to(dev), N).cpu()
         parity = float((gpu_raw - ref_raw).abs().max() / ref_raw.max())
         out["cpu_baseline"] = {"value": K * pn * pn / tmed, "unit": "source-pt*px/s", "cores": torch.get_num_threads(),
                                "kind": "port",
-                               "sample": f"{K} source points strided through the {S}-point list, full {pn}x{pn} grid, "
-                                         f"1 warm-up + 3 reps, median {tmed:.2f} s; oracle/abbe_oracle.py abbe_raw "
+                               "sample": f"{K} source points strided through the {S_full}-point list, full {pn}x{pn} grid"
+                                         + (f", plane {planes // 2} of {planes}" if planes > 1 else "") +
+                                         f", 1 warm-up + 3 reps, median {tmed:.2f} s; oracle/abbe_oracle.py abbe_raw "
                                          "(torch-CPU roll/mul/pad/fftshift/ifft2/ifftshift/crop/abs2/add)",
                                "gpu_vs_cpu_rel_to_max": parity}
 
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -108,15 +108,18 @@ int litho_mask_spectrum(const int16_t *geometry, int pn, double epsilon, int N, 
 /* ---- Introspection for bench.py / tests: what the last litho_abbe_accumulate on this
  * thread planned.  fields: [0]=mode (0 pruned box, 1 general/wrapping), [1]=box row0,
  * [2]=box col0, [3]=box rows, [4]=box cols, [5]=points per batch, [6]=x-pass launches,
- * [7]=kernel variant (-1 generic, else
- * log2(N/pn) of the pruned specialisation). */
-int litho_abbe_last_plan(int64_t fields_host[8]);
+ * [7]=kernel variant (-1 generic, else log2(N/pn) of the pruned specialisation), [8]=planes in flight per
+ * launch pair (through-focus stacks), [9]=y-pass groups per plane, [10]=source points per x-pass workgroup,
+ * [11]=1 when the plane-fused x-pass ran (mask-spectrum window gathered once per source point for all planes
+ * in flight). */
+int litho_abbe_last_plan(int64_t fields_host[12]);
 
 /* ---- Per-kernel timing for bench.py: when on, litho_abbe_accumulate brackets every x-pass
  * and y-pass launch with HIP events recorded on `stream` (at most 4096 launches per call)
  * and waits for the last one before returning.  fields: [0]=x-pass total ms, [1]=x-pass
- * launches, [2]=source points those launches covered, [3..5]=the same for the y-pass,
- * [6]=1 when the y-pass ran the wave-per-line kernel (k_ypass_wave) instead of k_ypass_acc. */
+ * batches (one batch = the x-pass launches of one launch pair), [2]=T items (source point x plane) they
+ * covered, [3..5]=the same for the y-pass, [6]=1 when the y-pass ran the wave-per-line kernel
+ * (k_ypass_wave) instead of k_ypass_acc, [7]=planes in flight per launch pair. */
 int litho_abbe_set_profiling(int on);
 int litho_abbe_last_profile(double fields_host[8]);
 

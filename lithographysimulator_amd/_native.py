@@ -49,6 +49,11 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
+        arch = handle.litho_target_arch()
+        if arch != b"gfx950" and os.environ.get("LITHO_ALLOW_DIAG") != "1":
+            # "gfx950-diag" = a timing-diagnostic build (scripts/build_variants.sh) whose results are wrong
+            raise RuntimeError(f"{LIB_PATH} reports target {arch!r}, not b'gfx950': refusing a diagnostic build "
+                               "(set LITHO_ALLOW_DIAG=1 for timing scripts only)")
         _lib = handle
     return _lib
 
@@ -130,9 +135,10 @@ def epsilon_n(deltaK, pixelSize, wavelength):
 
 
 def last_plan():
-    arr = (c_int64 * 8)()
+    arr = (c_int64 * 12)()
     lib().litho_abbe_last_plan(arr)
-    keys = ("general", "box_row0", "box_col0", "box_rows", "box_cols", "batch", "launches", "variant")
+    keys = ("general", "box_row0", "box_col0", "box_rows", "box_cols", "batch", "launches", "variant",
+            "planes_in_flight", "groups_per_plane", "xchunk", "fused_xpass")
     return dict(zip(keys, list(arr)))
 
 
@@ -145,4 +151,4 @@ def last_profile():
     lib().litho_abbe_last_profile(arr)
     return {"xpass_ms": arr[0], "xpass_launches": int(arr[1]), "xpass_points": int(arr[2]),
             "ypass_ms": arr[3], "ypass_launches": int(arr[4]), "ypass_points": int(arr[5]),
-            "ypass_kernel": "k_ypass_wave" if arr[6] else "k_ypass_acc"}
+            "ypass_kernel": "k_ypass_wave" if arr[6] else "k_ypass_acc", "planes_in_flight": int(arr[7])}

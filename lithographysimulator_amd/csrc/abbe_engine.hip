@@ -55,24 +55,41 @@ __global__ void k_plan_init(int* plan)
     if (threadIdx.x < 8) plan[threadIdx.x] = (threadIdx.x & 1) ? INT_MIN : INT_MAX;
 }
 
-__global__ void k_pupil_box(const float2* __restrict__ P, int pn, int planes, int* plan)
+// Bounding box of the non-zero pupil samples over all planes: grid (row blocks, planes), each block scans
+// BOX_ROWS_PER_BLOCK rows of one plane; one atomic quadruple per block that saw a non-zero.
+static constexpr int BOX_ROWS_PER_BLOCK = 8;
+__global__ __launch_bounds__(256) void k_pupil_box(const float2* __restrict__ P, int pn, int* plan)
 {
-    const int row = blockIdx.x;
-    int cmin = INT_MAX, cmax = INT_MIN;
-    for (int p = 0; p < planes; ++p) {
-        const float2* r = P + ((size_t)p * pn + row) * pn;
-        for (int cidx = threadIdx.x; cidx < pn; cidx += blockDim.x) {
-            const float2 v = r[cidx];
-            if (v.x != 0.f || v.y != 0.f) { cmin = min(cmin, cidx); cmax = max(cmax, cidx); }
+    __shared__ int red[4][4];
+    const int row0 = blockIdx.x * BOX_ROWS_PER_BLOCK;
+    const float2* plane = P + (size_t)blockIdx.y * pn * pn;
+    int rmin = INT_MAX, rmax = INT_MIN, cmin = INT_MAX, cmax = INT_MIN;
+    for (int row = row0; row < min(pn, row0 + BOX_ROWS_PER_BLOCK); ++row) {
+        const float2* r = plane + (size_t)row * pn;
+        for (int j = threadIdx.x; j < pn; j += blockDim.x) {
+            const float2 v = r[j];
+            if (v.x != 0.f || v.y != 0.f) {
+                rmin = min(rmin, row); rmax = max(rmax, row);
+                cmin = min(cmin, j); cmax = max(cmax, j);
+            }
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
-        cmin = min(cmin, __shfl_xor(cmin, off));
-        cmax = max(cmax, __shfl_xor(cmax, off));
+        rmin = min(rmin, __shfl_xor(rmin, off)); rmax = max(rmax, __shfl_xor(rmax, off));
+        cmin = min(cmin, __shfl_xor(cmin, off)); cmax = max(cmax, __shfl_xor(cmax, off));
     }
-    if ((threadIdx.x & 63) == 0 && cmax >= 0) {
-        atomicMin(&plan[0], row); atomicMax(&plan[1], row);
-        atomicMin(&plan[2], cmin); atomicMax(&plan[3], cmax);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wv][0] = rmin; red[wv][1] = rmax; red[wv][2] = cmin; red[wv][3] = cmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) {
+            rmin = min(rmin, red[i][0]); rmax = max(rmax, red[i][1]);
+            cmin = min(cmin, red[i][2]); cmax = max(cmax, red[i][3]);
+        }
+        if (rmax >= 0) {
+            atomicMin(&plan[0], rmin); atomicMax(&plan[1], rmax);
+            atomicMin(&plan[2], cmin); atomicMax(&plan[3], cmax);
+        }
     }
 }
 
@@ -93,10 +110,13 @@ __global__ void k_shift_extents(const int* __restrict__ shifts, long long S, int
     }
 }
 
-// out[qy][qx] += sum_g slab[g][qx][qy]   (32x32 tiles through LDS)
-__global__ void k_slab_reduce(const float* __restrict__ slab, float* __restrict__ out, int pn, int ldq, int G)
+// out[p][qy][qx] += sum_g slab[p * gstride + g][qx][qy]   (32x32 tiles through LDS; blockIdx.z = plane p)
+__global__ void k_slab_reduce(const float* __restrict__ slab, float* __restrict__ out, int pn, int ldq, int G,
+                              int gstride)
 {
     __shared__ float tile[32][33];
+    slab += (size_t)blockIdx.z * gstride * ldq * pn;
+    out += (size_t)blockIdx.z * pn * pn;
     const int qx0 = blockIdx.x * 32, qy0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 256 threads: ty in 0..7
     for (int j = ty; j < 32; j += 8) {
@@ -185,13 +205,32 @@ static int env_int(const char* name, int dflt)
     return (e && *e) ? atoi(e) : dflt;
 }
 
-static thread_local int64_t g_last_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+// Tuning / test knobs.  Read ONCE per C-ABI call (the parity tests flip them between calls), never per launch.
+struct Knobs {
+    int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk;
+    static Knobs read()
+    {
+        Knobs k;
+        k.force_generic = env_int("LITHO_ABBE_FORCE_GENERIC", 0);
+        k.force_general = env_int("LITHO_ABBE_FORCE_GENERAL", 0);
+        k.groups = env_int("LITHO_ABBE_GROUPS", 0);
+        k.batch = env_int("LITHO_ABBE_BATCH", 0);
+        k.xchunk = env_int("LITHO_ABBE_XCHUNK", 0);
+        k.tile = env_int("LITHO_ABBE_TILE", 4);
+        k.w64 = env_int("LITHO_ABBE_W64", 1);
+        k.w64_8192 = env_int("LITHO_ABBE_W64_8192", 0);
+        k.w64x = env_int("LITHO_ABBE_W64X", 0);
+        k.plane_chunk = env_int("LITHO_ABBE_PLANE_CHUNK", 0);
+        return k;
+    }
+};
+
+static thread_local int64_t g_last_plan[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 // Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's
 // roofline leg).  Off by default: the events serialise nothing but cost host time.
 static thread_local int g_profiling = 0;
 static thread_local double g_profile[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // x ms, x launches, x points, y ms, y launches, y points, -, -
-struct Mark { hipEvent_t ev; int kind; int nb; };   // kind: -1 start, 0 after an x-pass, 1 after a y-pass
 
 const SizeOps* size_ops_4(); const SizeOps* size_ops_5(); const SizeOps* size_ops_6(); const SizeOps* size_ops_7();
 const SizeOps* size_ops_8(); const SizeOps* size_ops_9(); const SizeOps* size_ops_10(); const SizeOps* size_ops_11();
@@ -209,14 +248,14 @@ const SizeOps* size_ops(int log2n)
 }
 
 // Which specialised kernel variant fits this geometry (-1 = generic).
-static int pick_variant(const PassGeom& g)
+static int pick_variant(const PassGeom& g, const Knobs& kn)
 {
     if (g.general || (g.pn & (g.pn - 1))) return -1;
     const int rl = ilog2(g.N) - ilog2(g.pn);
     if (rl < 0 || rl > 2) return -1;
     const unsigned nat = natural_in_mask(rl);
     if ((g.xmask & ~nat) || (g.ymask & ~nat)) return -1;
-    return env_int("LITHO_ABBE_FORCE_GENERIC", 0) ? -1 : rl;
+    return kn.force_generic ? -1 : rl;
 }
 
 // Reads the 8 plan words back (one small synchronising copy).
@@ -228,9 +267,8 @@ static int read_plan(const Workspace& w, int host[8], hipStream_t st)
 }
 
 // T tile width (columns): 4 unless LITHO_ABBE_TILE says 8 or 16 (tuning knob)
-static void set_tile(PassGeom& g, int rows)
+static void set_tile(PassGeom& g, int rows, int tc = 4)
 {
-    const int tc = env_int("LITHO_ABBE_TILE", 4);
     g.tcl = (tc == 16) ? 4 : (tc == 8) ? 3 : 2;
     const long long ntile = (g.pn + (1 << g.tcl) - 1) >> g.tcl;
     g.t_point = (ntile * rows) << g.tcl;
@@ -250,7 +288,7 @@ static unsigned slot_mask(int N, int lo, int hi)
     return m;
 }
 
-static void make_geom(PassGeom& g, int pn, int N, int r0, int c0, int h, int wdt, int general)
+static void make_geom(PassGeom& g, int pn, int N, int r0, int c0, int h, int wdt, int general, int tile_cols = 4)
 {
     g.pn = pn; g.c = pn / 2; g.N = N; g.nt = (pn + 3) / 4;
     g.kx0 = c0 - g.c; g.kx1 = c0 + wdt - g.c;
@@ -258,8 +296,27 @@ static void make_geom(PassGeom& g, int pn, int N, int r0, int c0, int h, int wdt
     g.rows = h; g.general = general;
     g.xmask = slot_mask(N, g.kx0, g.kx1);
     g.ymask = slot_mask(N, g.ky0, g.ky1);
-    set_tile(g, h);
+    set_tile(g, h, tile_cols);
 }
+
+// HIP events of one profiled call; destroyed on every exit path.
+struct Mark { hipEvent_t ev; int kind; int items; };   // kind: -1 start, 0 after an x-pass, 1 after a y-pass
+struct MarkList {
+    static constexpr size_t MAX = 8192;                // = 4096 launch pairs per call
+    std::vector<Mark> v;
+    bool on;
+    hipStream_t st;
+    MarkList(bool on_, hipStream_t st_) : on(on_), st(st_) {}
+    ~MarkList() { for (auto& m : v) (void)hipEventDestroy(m.ev); }
+    void add(int kind, int items)
+    {
+        if (!on || v.size() >= MAX) return;
+        Mark m{nullptr, kind, items};
+        if (hipEventCreate(&m.ev) != hipSuccess) return;
+        (void)hipEventRecord(m.ev, st);
+        v.push_back(m);
+    }
+};
 
 static int abbe_accumulate(const float2* M, const float2* P, int planes, const int* shifts, int64_t S,
                            int pn, int N, float* out, void* ws, size_t ws_bytes, hipStream_t st)
@@ -270,10 +327,12 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     if (S == 0) return LITHO_OK;
     Workspace w;
     if (!carve(ws, ws_bytes, pn, N, w)) return LITHO_E_WORKSPACE;
+    const Knobs kn = Knobs::read();
 
     hipLaunchKernelGGL(k_twiddle_table, dim3((N + 255) / 256), dim3(256), 0, st, w.twtab, N);
     hipLaunchKernelGGL(k_plan_init, dim3(1), dim3(64), 0, st, w.plan);
-    hipLaunchKernelGGL(k_pupil_box, dim3(pn), dim3(256), 0, st, P, pn, planes, w.plan);
+    hipLaunchKernelGGL(k_pupil_box, dim3((pn + BOX_ROWS_PER_BLOCK - 1) / BOX_ROWS_PER_BLOCK, planes), dim3(256), 0, st,
+                       P, pn, w.plan);
     hipLaunchKernelGGL(k_shift_extents, dim3(256), dim3(256), 0, st, shifts, (long long)S, w.plan);
     HIP_TRY(hipGetLastError());
     int pl[8];
@@ -284,109 +343,133 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     int r0 = pl[0], h = pl[1] - pl[0] + 1, c0 = pl[2], wdt = pl[3] - pl[2] + 1;
     const bool nowrap = (r0 + pl[4] >= 0) && (r0 + h - 1 + pl[5] <= pn - 1) &&
                         (c0 + pl[6] >= 0) && (c0 + wdt - 1 + pl[7] <= pn - 1);
-    int general = (!nowrap || env_int("LITHO_ABBE_FORCE_GENERAL", 0)) ? 1 : 0;
+    int general = (!nowrap || kn.force_general) ? 1 : 0;
     if (general) { r0 = 0; c0 = 0; h = pn; wdt = pn; }
     PassGeom g;
-    make_geom(g, pn, N, r0, c0, h, wdt, general);
+    make_geom(g, pn, N, r0, c0, h, wdt, general, kn.tile);
+    const SizeOps* ops = size_ops(ilog2(N));
+    if (!ops) return LITHO_E_ARG;
+    const int variant = pick_variant(g, kn);
 
-    // y-pass groups: the grid is (tile blocks) x G workgroups; pick the smallest G that makes it a whole
-    // number of full-occupancy rounds (256 CUs x workgroups per CU), so no round runs part-empty.
+    // y-pass groups: the grid is (tile blocks) x (planes in flight) x G workgroups; pick the smallest group
+    // count that makes it a whole number of full-occupancy rounds (256 CUs x workgroups per CU).
     const int l2n = ilog2(N);
     const int lines_per_wg = (N / 16 >= 64) ? 1 : 64 / (N / 16);
-    // (the wave-per-line y-pass used at 2048^2 keeps 2 workgroups per CU resident)
     // wave-per-line y-pass (k_ypass_wave): N = 2 pn with pn = 512, 1024, 2048; pn = 4096 is opt-in (slower there)
-    const bool w64_ok = (pn * 2 == N) && (N == 1024 || N == 2048 || N == 4096 ||
-                                          (N == 8192 && env_int("LITHO_ABBE_W64_8192", 0)));
-    const bool w64_shape = w64_ok && env_int("LITHO_ABBE_W64", 1);
+    const bool w64_ok = (pn * 2 == N) && (N == 1024 || N == 2048 || N == 4096 || (N == 8192 && kn.w64_8192));
+    const bool w64_shape = w64_ok && kn.w64;
+    const bool use_w64 = variant == 1 && w64_shape && g.tcl == 2;
     const int wave_tiles = (N == 1024) ? 2 : 1;                       // T tiles per wave-kernel workgroup
     const int tile_blocks = w64_shape ? (g.nt + wave_tiles - 1) / wave_tiles : (g.nt + lines_per_wg - 1) / lines_per_wg;
     const int resident = 256 * (w64_shape ? (N <= 2048 ? 4 : (N == 4096 ? 2 : 1)) : l2n <= 12 ? 3 : (l2n == 13 ? 2 : 1));
     int a_ = tile_blocks, b_ = resident;
     while (b_) { const int t_ = a_ % b_; a_ = b_; b_ = t_; }
-    int G = resident / a_;
-    const int g_env = env_int("LITHO_ABBE_GROUPS", 0);
-    if (g_env > 0) G = g_env;
+    int Gtot = resident / a_;                                  // groups that fill whole rounds
+    if (kn.groups > 0) Gtot = kn.groups;
+    if (Gtot < 1) Gtot = 1;
+    if (Gtot > g_cap(pn)) Gtot = g_cap(pn);
+
+    // Through-focus stacks: PC planes are in flight per launch pair.  The fused x-pass gathers the mask-spectrum
+    // window of a source point once for all of them (NP = 4 / 2 / 1 planes per workgroup); the y-pass gives every
+    // plane its own groups and slabs.  PC = 4 unless the stack is smaller (measured at 2048^2 x 32 planes).
+    int PC = planes < 4 ? planes : 4;
+    if (kn.plane_chunk > 0) PC = kn.plane_chunk < planes ? kn.plane_chunk : planes;
+    if (PC > g_cap(pn)) PC = g_cap(pn);
+    int G = Gtot / PC;                                         // groups per plane
     if (G < 1) G = 1;
-    if (G > g_cap(pn)) G = g_cap(pn);
-    // Batch = source points per x-pass/y-pass launch pair.  The intermediate T of one batch should stay
-    // resident in the 256 MiB Infinity Cache between the two passes (measured at 2048^2: 63 points = 1 GiB
-    // -> 28.7 us/point, 16 points = 270 MB -> 21.9), and a y-pass workgroup needs >= ~8 points to
-    // amortise its accumulator flush.
-    const size_t point_bytes = (size_t)g.t_point * sizeof(float2);
-    int64_t bs = (int64_t)(w.t_bytes / point_bytes);
-    int64_t bs_cache = (int64_t)(((size_t)288 << 20) / point_bytes);
-    if (bs_cache < 8) bs_cache = 8;
-    if (bs > bs_cache) bs = bs_cache;
-    const int bs_env = env_int("LITHO_ABBE_BATCH", 0);
-    if (bs_env > 0) bs = (bs_env < (int64_t)(w.t_bytes / point_bytes)) ? bs_env : (int64_t)(w.t_bytes / point_bytes);
-    if (bs < 1) return LITHO_E_WORKSPACE;
+    const bool fused_x = !general && variant >= 0 && !(use_w64 && N == 4096 && kn.w64x);
+
+    // Batch = source points per launch pair.  The intermediate T of one batch (PC planes x points) should stay
+    // resident in the 256 MiB Infinity Cache between the two passes (measured at 2048^2: 63 items = 1 GiB ->
+    // 28.7 us/item, 16 items = 270 MB -> 21.9), and a y-pass workgroup wants several points per plane to amortise
+    // its accumulator flush.
+    const size_t item_bytes = (size_t)g.t_point * sizeof(float2);
+    const int64_t items_ws = (int64_t)(w.t_bytes / item_bytes);
+    int64_t items = items_ws;
+    int64_t items_cache = (int64_t)(((size_t)288 << 20) / item_bytes);
+    if (items_cache < 8) items_cache = 8;
+    if (items > items_cache) items = items_cache;
+    if (items_ws < 1) return LITHO_E_WORKSPACE;
+    if (PC > items_ws) PC = (int)items_ws;
+    int64_t bs = items / PC;
+    if (kn.batch > 0) bs = kn.batch;
+    if (bs > items_ws / PC) bs = items_ws / PC;
+    if (bs < 1) bs = 1;
     if (bs > 65535) bs = 65535;
     // Balance: every y-pass group gets the same number of points (batch multiple of G) and the x-pass
     // chunks divide the batch evenly (chunk = divisor of the batch nearest 4).
-    if (bs_env <= 0 && bs > G) bs -= bs % G;
-    int xchunk = env_int("LITHO_ABBE_XCHUNK", 0);       // source points per x-pass workgroup
+    if (kn.batch <= 0 && bs > G) bs -= bs % G;
+    int xchunk = kn.xchunk;                                    // source points per x-pass workgroup
     if (xchunk <= 0) {
-        xchunk = 4;
-        for (int cand : {4, 5, 3, 6, 2}) if (bs % cand == 0) { xchunk = cand; break; }
+        const int want = PC >= 4 ? 1 : (PC >= 2 ? 2 : 4);      // ~4 transforms per workgroup
+        xchunk = want;
+        if (want == 4) for (int cand : {4, 5, 3, 6, 2}) if (bs % cand == 0) { xchunk = cand; break; }
+        if (want == 2) for (int cand : {2, 3, 1}) if (bs % cand == 0) { xchunk = cand; break; }
     }
     const size_t slab_plane = (size_t)g.nt * 4 * pn;
-    const SizeOps* ops = size_ops(ilog2(N));
-    if (!ops) return LITHO_E_ARG;
-    const int variant = pick_variant(g);
-    const bool use_w64 = variant == 1 && w64_shape && g.tcl == 2;
     int64_t nx = 0;
-    // profiling: ONE event per kernel boundary (E0 x E1 y E2 x E3 ...); consecutive events bracket
-    // exactly one launch.  (Two events recorded back to back alias on ROCm, so no begin/end pairs.)
-    std::vector<Mark> marks;
-    const size_t max_marks = 8192;
-    auto mark = [&](int kind, int nb) {
-        if (!g_profiling || marks.size() >= max_marks) return;
-        Mark m{nullptr, kind, nb};
-        if (hipEventCreate(&m.ev) != hipSuccess) return;
-        (void)hipEventRecord(m.ev, st);
-        marks.push_back(m);
-    };
-    for (int p = 0; p < planes; ++p) {
-        const float2* Pp = P + (size_t)p * pn * pn;
-        HIP_TRY(hipMemsetAsync(w.slab, 0, (size_t)G * slab_plane * sizeof(float), st));
+    // profiling: ONE event per kernel-class boundary (E0 x E1 y E2 x E3 ...); consecutive events bracket the
+    // launches of one pass over one batch.  (Two events recorded back to back alias on ROCm, so no begin/end pairs.)
+    MarkList marks(g_profiling != 0, st);
+    for (int p0 = 0; p0 < planes; p0 += PC) {
+        const int pc = (planes - p0 < PC) ? planes - p0 : PC;
+        const float2* Pc = P + (size_t)p0 * pn * pn;
+        HIP_TRY(hipMemsetAsync(w.slab, 0, (size_t)pc * G * slab_plane * sizeof(float), st));
+        bool fresh = true;                                     // start a new timing interval after memset / reduce
         for (int64_t s0 = 0; s0 < S; s0 += bs) {
             const int nb = (int)((S - s0 < bs) ? (S - s0) : bs);
-            if (marks.empty()) mark(-1, 0);
-            if (general) {
-                AbbeLoader ld{Pp, M, shifts + 2 * s0, nullptr, nullptr, 0, 0};
-                HIP_TRY(ops->xpass_general(ld, w.T, w.twtab, g, nb, st));
-            } else if (use_w64 && N == 4096 && env_int("LITHO_ABBE_W64X", 0)) {
-                HIP_TRY(ops->xpass_w64(Pp, M, shifts + 2 * s0, w.T, w.twtab, g, nb, st));
+            const int* sh = shifts + 2 * s0;
+            if (fresh) { marks.add(-1, 0); fresh = false; }
+            if (fused_x) {
+                for (int q = 0; q < pc;) {
+                    const int np = variant == 0 ? 1 : (pc - q >= 4) ? 4 : (pc - q >= 2 ? 2 : 1);
+                    HIP_TRY(ops->xpass_abbe(variant, np, Pc + (size_t)q * pn * pn, M, sh,
+                                            w.T + (size_t)q * nb * g.t_point, w.twtab, g, nb, xchunk, st));
+                    q += np;
+                }
             } else {
-                HIP_TRY(ops->xpass_abbe(variant, Pp, M, shifts + 2 * s0, w.T, w.twtab, g, nb, xchunk, st));
+                for (int q = 0; q < pc; ++q) {
+                    const float2* Pq = Pc + (size_t)q * pn * pn;
+                    float2* Tq = w.T + (size_t)q * nb * g.t_point;
+                    if (general) {
+                        AbbeLoader ld{Pq, M, sh, nullptr, nullptr, 0, 0};
+                        HIP_TRY(ops->xpass_general(ld, Tq, w.twtab, g, nb, st));
+                    } else if (variant >= 0) {
+                        HIP_TRY(ops->xpass_w64(Pq, M, sh, Tq, w.twtab, g, nb, st));
+                    } else {
+                        HIP_TRY(ops->xpass_abbe(-1, 1, Pq, M, sh, Tq, w.twtab, g, nb, xchunk, st));
+                    }
+                }
             }
-            mark(0, nb);
+            marks.add(0, nb * pc);
             const int Geff = nb < G ? nb : G;
-            if (use_w64) HIP_TRY(ops->ypass_w64(w.T, w.slab, w.twtab, g, nb, Geff, st));
-            else HIP_TRY(ops->ypass_acc(variant, w.T, w.slab, w.twtab, g, nb, Geff, st));
-            mark(1, nb);
+            if (use_w64) HIP_TRY(ops->ypass_w64(w.T, w.slab, w.twtab, g, nb, pc, Geff, G, st));
+            else HIP_TRY(ops->ypass_acc(variant, w.T, w.slab, w.twtab, g, nb, pc, Geff, G, st));
+            marks.add(1, nb * pc);
             ++nx;
         }
-        hipLaunchKernelGGL(k_slab_reduce, dim3((pn + 31) / 32, (pn + 31) / 32), dim3(256), 0, st,
-                           w.slab, out + (size_t)p * pn * pn, pn, g.nt * 4, G);
+        hipLaunchKernelGGL(k_slab_reduce, dim3((pn + 31) / 32, (pn + 31) / 32, pc), dim3(256), 0, st,
+                           w.slab, out + (size_t)p0 * pn * pn, pn, g.nt * 4, G, G);
         HIP_TRY(hipGetLastError());
     }
     if (g_profiling) {
         for (int i = 0; i < 8; ++i) g_profile[i] = 0;
-        if (!marks.empty()) (void)hipEventSynchronize(marks.back().ev);
-        for (size_t i = 1; i < marks.size(); ++i) {
+        if (!marks.v.empty()) (void)hipEventSynchronize(marks.v.back().ev);
+        for (size_t i = 1; i < marks.v.size(); ++i) {
             float ms = 0.f;
-            if (marks[i].kind >= 0 && hipEventElapsedTime(&ms, marks[i - 1].ev, marks[i].ev) == hipSuccess) {
-                g_profile[marks[i].kind * 3 + 0] += ms;
-                g_profile[marks[i].kind * 3 + 1] += 1;
-                g_profile[marks[i].kind * 3 + 2] += marks[i].nb;
+            const Mark& m = marks.v[i];
+            if (m.kind >= 0 && hipEventElapsedTime(&ms, marks.v[i - 1].ev, m.ev) == hipSuccess) {
+                g_profile[m.kind * 3 + 0] += ms;
+                g_profile[m.kind * 3 + 1] += 1;
+                g_profile[m.kind * 3 + 2] += m.items;
             }
         }
-        for (auto& m : marks) (void)hipEventDestroy(m.ev);
         g_profile[6] = use_w64 ? 1 : 0;
+        g_profile[7] = PC;
     }
     g_last_plan[0] = general; g_last_plan[1] = r0; g_last_plan[2] = c0; g_last_plan[3] = h;
     g_last_plan[4] = wdt; g_last_plan[5] = bs; g_last_plan[6] = nx; g_last_plan[7] = variant;
+    g_last_plan[8] = PC; g_last_plan[9] = G; g_last_plan[10] = xchunk; g_last_plan[11] = fused_x ? 1 : 0;
     return LITHO_OK;
 }
 
@@ -400,7 +483,7 @@ static int abbe_field(const float2* pf, const float2* M, int pn, int N, float2* 
     if (!carve(ws, ws_bytes, pn, N, w)) return LITHO_E_WORKSPACE;
     hipLaunchKernelGGL(k_twiddle_table, dim3((N + 255) / 256), dim3(256), 0, st, w.twtab, N);
     hipLaunchKernelGGL(k_plan_init, dim3(1), dim3(64), 0, st, w.plan);
-    hipLaunchKernelGGL(k_pupil_box, dim3(pn), dim3(256), 0, st, pf, pn, 1, w.plan);
+    hipLaunchKernelGGL(k_pupil_box, dim3((pn + BOX_ROWS_PER_BLOCK - 1) / BOX_ROWS_PER_BLOCK, 1), dim3(256), 0, st, pf, pn, w.plan);
     HIP_TRY(hipGetLastError());
     int pl[8];
     rc = read_plan(w, pl, st);
@@ -511,7 +594,7 @@ int litho_abbe_last_profile(double fields_host[8])
     return LITHO_OK;
 }
 
-int litho_abbe_last_plan(int64_t fields_host[8])
+int litho_abbe_last_plan(int64_t fields_host[12])
 {
     if (!fields_host) return LITHO_E_ARG;
     memcpy(fields_host, litho::g_last_plan, sizeof(litho::g_last_plan));

@@ -17,6 +17,10 @@ void set_last_error(const char* what, hipError_t e)
 
 extern "C" {
 int litho_version(void) { return 100; }
+#ifdef LITHO_DIAG_BUILD
+const char* litho_target_arch(void) { return "gfx950-diag"; }      // timing-diagnostic build: results may be wrong
+#else
 const char* litho_target_arch(void) { return "gfx950"; }
+#endif
 const char* litho_last_error(void) { return litho::g_err; }
 }

@@ -99,11 +99,14 @@ __device__ __forceinline__ void diag_keep(float2 v, unsigned o) { asm volatile("
 // T[s][tile][row][4].  One workgroup = one row of the box for a CHUNK of source points: the
 // pupil row and the twiddles stay in registers, only the mask-spectrum window moves.
 // ----------------------------------------------------------------------------------
-template <int LOG2N, int RL, bool PRUNED>
+template <int LOG2N, int RL, bool PRUNED, int NP>
 __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void k_xpass_abbe(
     const float2* __restrict__ P, const float2* __restrict__ M, const int* __restrict__ shifts,
     float2* __restrict__ Tbuf, const float2* __restrict__ twtab, PassGeom g, int nb, int chunk)
 {
+    // NP = planes of a through-focus stack handled by this workgroup (P points at the first of them,
+    // planes are pn*pn apart).  The mask-spectrum window of a source point is gathered ONCE and multiplied by
+    // the NP pupil rows held in registers; T item (plane p, point s) = p * nb + s.
     using F = LineFFT<LOG2N, +1>;
     using LC = Launch<LOG2N>;
     constexpr unsigned IN = PRUNED ? natural_in_mask(RL) : 0xFFFFu;
@@ -131,21 +134,28 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
     const bool active = a < g.rows;
     const int r = g.ky0 + g.c + a;                            // row of P inside its support box
     const size_t plane_bytes = (size_t)g.pn * g.pn * sizeof(float2);
-    const __amdgpu_buffer_rsrc_t rP = make_rsrc(P, plane_bytes);
     const __amdgpu_buffer_rsrc_t rM = make_rsrc(M, plane_bytes);
 
     unsigned koff[16];           // (c + k) of slot e, or BUF_OOB when outside the window
-    float2 pv[16];
+    float2 pv[NP][16];
     static_for<0, 16>([&](auto e_) {
         constexpr int e = decltype(e_)::value;
         if constexpr ((IN >> e) & 1u) {
             int k;
             const bool ok = centred_index(lt + F::T * e, F::N, g.kx0, g.kx1, k) && active;
             koff[e] = ok ? (unsigned)(g.c + k) : BUF_OOB;
-            pv[e] = buf_load_c64(rP, ok ? ((unsigned)r * g.pn + koff[e]) * 8u : BUF_OOB);
         }
     });
-    unsigned toff[16];           // byte offset of output bin m inside one source point's T block
+    static_for<0, NP>([&](auto p_) {
+        constexpr int p = decltype(p_)::value;
+        const __amdgpu_buffer_rsrc_t rP = make_rsrc(P + (size_t)p * g.pn * g.pn, plane_bytes);
+        static_for<0, 16>([&](auto e_) {
+            constexpr int e = decltype(e_)::value;
+            if constexpr ((IN >> e) & 1u)
+                pv[p][e] = buf_load_c64(rP, koff[e] != BUF_OOB ? ((unsigned)r * g.pn + koff[e]) * 8u : BUF_OOB);
+        });
+    });
+    unsigned toff[16];           // byte offset of output bin m inside one T item
     static_for<0, 16>([&](auto m_) {
         constexpr int m = decltype(m_)::value;
         if constexpr ((OUT >> m) & 1u) {
@@ -158,8 +168,7 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
 
     const int s_begin = blockIdx.y * chunk;
     const int s_end = min(nb, s_begin + chunk);
-    float2 mv[16];
-    auto load_window = [&](int s) {
+    auto load_window = [&](int s, float2 (&mv)[16]) {
         const int dy = shifts[2 * s], dx = shifts[2 * s + 1];
         const unsigned mrow = (unsigned)(r + dy) * g.pn + dx;          // same window of M moved by the shift
         static_for<0, 16>([&](auto e_) {
@@ -174,26 +183,42 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
     };
 
     int flip = 0;
+    float2 mnext[16];
+    if (s_begin < s_end) load_window(s_begin, mnext);
     for (int s = s_begin; s < s_end; ++s) {
-        load_window(s);
-        float2 x[16];
+        float2 mv[16];
         static_for<0, 16>([&](auto e_) {
             constexpr int e = decltype(e_)::value;
-            if constexpr ((IN >> e) & 1u) x[e] = cmul(pv[e], mv[e]);
-            else x[e] = make_float2(0.f, 0.f);
+            if constexpr ((IN >> e) & 1u) mv[e] = mnext[e];
         });
-        F::template run<LC::NBUF>(x, tw, lds, lt, flip);
-        const __amdgpu_buffer_rsrc_t rT =
-            make_rsrc(Tbuf + (size_t)s * g.t_point, (size_t)g.t_point * sizeof(float2));
-        static_for<0, 16>([&](auto m_) {
-            constexpr int m = decltype(m_)::value;
-#ifdef LITHO_DIAG_XNOSTORE
-            if constexpr ((OUT >> m) & 1u) diag_keep(x[m], toff[m]);
-#elif defined(LITHO_DIAG_XSTORE_L2)
-            if constexpr ((OUT >> m) & 1u) buf_store_c64(rT, toff[m] == BUF_OOB ? BUF_OOB : (toff[m] & 0xFFFFFu), x[m]);
+#ifndef LITHO_XPASS_NO_PREFETCH
+        // the next point's window is in flight while this point's NP transforms run (the LDS-only
+        // barriers of the FFT do not drain vmcnt); the last iteration re-reads its own window
+        load_window(s + 1 < s_end ? s + 1 : s, mnext);
 #else
-            if constexpr ((OUT >> m) & 1u) buf_store_c64(rT, toff[m], x[m]);
+        if (s + 1 < s_end) load_window(s + 1, mnext);
 #endif
+        static_for<0, NP>([&](auto p_) {
+            constexpr int p = decltype(p_)::value;
+            float2 x[16];
+            static_for<0, 16>([&](auto e_) {
+                constexpr int e = decltype(e_)::value;
+                if constexpr ((IN >> e) & 1u) x[e] = cmul(pv[p][e], mv[e]);
+                else x[e] = make_float2(0.f, 0.f);
+            });
+            F::template run<LC::NBUF>(x, tw, lds, lt, flip);
+            const __amdgpu_buffer_rsrc_t rT =
+                make_rsrc(Tbuf + ((size_t)p * nb + s) * g.t_point, (size_t)g.t_point * sizeof(float2));
+            static_for<0, 16>([&](auto m_) {
+                constexpr int m = decltype(m_)::value;
+#ifdef LITHO_DIAG_XNOSTORE
+                if constexpr ((OUT >> m) & 1u) diag_keep(x[m], toff[m]);
+#elif defined(LITHO_DIAG_XSTORE_L2)
+                if constexpr ((OUT >> m) & 1u) buf_store_c64(rT, toff[m] == BUF_OOB ? BUF_OOB : (toff[m] & 0xFFFFFu), x[m]);
+#else
+                if constexpr ((OUT >> m) & 1u) buf_store_c64(rT, toff[m], x[m]);
+#endif
+            });
         });
     }
 }
@@ -291,8 +316,10 @@ struct RealImageLoader {
 template <int LOG2N, int RL, bool PRUNED>
 __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void k_ypass_acc(
     const float2* __restrict__ Tbuf, float* __restrict__ slab, const float2* __restrict__ twtab,
-    PassGeom g, int nb, int G)
+    PassGeom g, int nb, int G, int gstride)
 {
+    // blockIdx.y = plane * G + sub: group `sub` of plane `plane` takes the points sub, sub + G, ... of the
+    // batch (T items plane * nb + s) and owns slab plane * gstride + sub.
     using F = LineFFT<LOG2N, +1>;
     using LC = Launch<LOG2N>;
     constexpr unsigned IN = PRUNED ? natural_in_mask(RL) : 0xFFFFu;
@@ -307,7 +334,9 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
 
     const int tile = blockIdx.x * LC::L + lg;
     const bool active = tile < g.nt;
-    const int grp = blockIdx.y;
+    const int plane = blockIdx.y / G, grp = blockIdx.y - plane * G;
+    Tbuf += (size_t)plane * nb * g.t_point;
+    slab += (size_t)plane * gstride * g.nt * 4 * g.pn;
 
     float acc[4][16];
     static_for<0, 4>([&](auto c_) {
@@ -488,7 +517,7 @@ struct WaveShape {
 template <int LOG2N>
 __global__ __launch_bounds__(WaveShape<LOG2N>::THREADS, WaveShape<LOG2N>::MINWAVES) void k_ypass_wave(
     const float2* __restrict__ Tbuf, float* __restrict__ slab, const float2* __restrict__ twtab,
-    PassGeom g, int nb, int G)
+    PassGeom g, int nb, int G, int gstride)
 {
     using WS = WaveShape<LOG2N>;
     using W = typename WS::W;
@@ -508,7 +537,10 @@ __global__ __launch_bounds__(WaveShape<LOG2N>::THREADS, WaveShape<LOG2N>::MINWAV
     // The tile index is wave-uniform (a wave's units cover at most one tile); readfirstlane makes that
     // provable, otherwise every buffer access through the tile's descriptor becomes a waterfall loop.
     const int tile = blockIdx.x * WS::TILES + (WS::TILES > 1 ? __builtin_amdgcn_readfirstlane(colg >> 2) : 0);
-    const int col = colg & 3, grp = blockIdx.y;
+    const int col = colg & 3;
+    const int plane = blockIdx.y / G, grp = blockIdx.y - plane * G;      // see k_ypass_acc
+    Tbuf += (size_t)plane * nb * g.t_point;
+    slab += (size_t)plane * gstride * g.nt * 4 * g.pn;
     const bool active = tile < g.nt;
     float acc[S / 2];
     static_for<0, S / 2>([&](auto i) { acc[i] = 0.f; });
@@ -605,62 +637,93 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
 // per-FFT-size launch table (one translation unit per size, see inst_*.hip)
 // ----------------------------------------------------------------------------------
 struct SizeOps {
-    // variant: -1 = generic (any even pn, runtime predication); 0/1/2 = pruned, RL = log2(N/pn)
-    hipError_t (*xpass_abbe)(int variant, const float2* P, const float2* M, const int* shifts, float2* T,
+    // variant: -1 = generic (any even pn, runtime predication); 0/1/2 = pruned, RL = log2(N/pn).
+    // np = planes fused into the launch (1, 2 or 4; the generic variant takes 1 only): P points at the first
+    // plane, T item (p, s) = p * nb + s.
+    hipError_t (*xpass_abbe)(int variant, int np, const float2* P, const float2* M, const int* shifts, float2* T,
                              const float2* tw, const PassGeom& g, int nb, int chunk, hipStream_t st);
     hipError_t (*xpass_general)(const AbbeLoader& ld, float2* T, const float2* tw, const PassGeom& g, int nb,
                                 hipStream_t st);
     hipError_t (*xpass_real_fwd)(const RealImageLoader& ld, float2* T, const float2* tw, const PassGeom& g,
                                  hipStream_t st);
+    // y-pass over `planes` planes x G groups per plane (grid.y = planes * G); slab of (plane, group) =
+    // plane * gstride + group
     hipError_t (*ypass_acc)(int variant, const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb,
-                            int G, hipStream_t st);
+                            int planes, int G, int gstride, hipStream_t st);
     hipError_t (*ypass_field)(int sign, const float2* T, float2* field, const float2* tw, const PassGeom& g,
                               hipStream_t st);
     // wave-per-line passes (y: N = 1024..8192 with pn = N/2, pruned only; x: N = 4096); hipErrorNotSupported otherwise
     hipError_t (*xpass_w64)(const float2* P, const float2* M, const int* shifts, float2* T, const float2* tw,
                             const PassGeom& g, int nb, hipStream_t st);
-    hipError_t (*ypass_w64)(const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb, int G,
-                            hipStream_t st);
+    hipError_t (*ypass_w64)(const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb, int planes,
+                            int G, int gstride, hipStream_t st);
 };
 const SizeOps* size_ops(int log2n);      // nullptr outside 4..14
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is needed once per kernel and device, not once per launch
+// (a config-3 image is ~23,000 launches).  One LdsOnce lives in each launcher; bit d = done on device d.
+struct LdsOnce {
+    unsigned done = 0;
+};
 template <typename K>
-static hipError_t set_lds(K kern, size_t bytes)
+static hipError_t set_lds(LdsOnce& once, K kern, size_t bytes)
 {
-    return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned bit = 1u << (dev & 31);
+    if (__atomic_load_n(&once.done, __ATOMIC_ACQUIRE) & bit) return hipSuccess;
+    e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) __atomic_fetch_or(&once.done, bit, __ATOMIC_RELEASE);
+    return e;
 }
 
 template <int LOG2N>
 struct SizeImpl {
     using LC = Launch<LOG2N>;
 
-    template <int RL, bool PRUNED>
+    template <int RL, bool PRUNED, int NP>
     static hipError_t xa(const float2* P, const float2* M, const int* shifts, float2* T, const float2* tw,
                          const PassGeom& g, int nb, int chunk, hipStream_t st)
     {
-        auto kern = k_xpass_abbe<LOG2N, RL, PRUNED>;
-        hipError_t e = set_lds(kern, LC::LDS_BYTES);
+        static LdsOnce once;
+        auto kern = k_xpass_abbe<LOG2N, RL, PRUNED, NP>;
+        hipError_t e = set_lds(once, kern, LC::LDS_BYTES);
         if (e != hipSuccess) return e;
         // L == 1: grid.x padded to a multiple of 32 for the XCD-aware row mapping in the kernel
         dim3 grid(LC::L == 1 ? (g.rows + 31) / 32 * 32 : (g.rows + LC::L - 1) / LC::L, (nb + chunk - 1) / chunk);
         hipLaunchKernelGGL(kern, grid, dim3(LC::THREADS), LC::LDS_BYTES, st, P, M, shifts, T, tw, g, nb, chunk);
         return hipGetLastError();
     }
-    static hipError_t xpass_abbe(int variant, const float2* P, const float2* M, const int* shifts, float2* T,
+    template <int RL>
+    static hipError_t xa_np(int np, const float2* P, const float2* M, const int* shifts, float2* T, const float2* tw,
+                            const PassGeom& g, int nb, int chunk, hipStream_t st)
+    {
+        if (np == 1) return xa<RL, true, 1>(P, M, shifts, T, tw, g, nb, chunk, st);
+        if constexpr (RL >= 1) {       // RL = 0 (N = pn) has 9 live input slots: 2 or 4 pupil rows would spill
+            if (np == 2) return xa<RL, true, 2>(P, M, shifts, T, tw, g, nb, chunk, st);
+            if (np == 4) return xa<RL, true, 4>(P, M, shifts, T, tw, g, nb, chunk, st);
+        }
+        return hipErrorInvalidValue;
+    }
+    static hipError_t xpass_abbe(int variant, int np, const float2* P, const float2* M, const int* shifts, float2* T,
                                  const float2* tw, const PassGeom& g, int nb, int chunk, hipStream_t st)
     {
         switch (variant) {
-            case 0: return xa<0, true>(P, M, shifts, T, tw, g, nb, chunk, st);
-            case 1: return xa<1, true>(P, M, shifts, T, tw, g, nb, chunk, st);
-            case 2: return xa<2, true>(P, M, shifts, T, tw, g, nb, chunk, st);
-            default: return xa<-1, false>(P, M, shifts, T, tw, g, nb, chunk, st);
+            case 0: return xa_np<0>(np, P, M, shifts, T, tw, g, nb, chunk, st);
+            case 1: return xa_np<1>(np, P, M, shifts, T, tw, g, nb, chunk, st);
+            case 2: return xa_np<2>(np, P, M, shifts, T, tw, g, nb, chunk, st);
+            default:
+                if (np != 1) return hipErrorInvalidValue;
+                return xa<-1, false, 1>(P, M, shifts, T, tw, g, nb, chunk, st);
         }
     }
     static hipError_t xpass_general(const AbbeLoader& ld, float2* T, const float2* tw, const PassGeom& g, int nb,
                                     hipStream_t st)
     {
+        static LdsOnce once;
         auto kern = k_xpass<LOG2N, +1, AbbeLoader>;
-        hipError_t e = set_lds(kern, LC::LDS_BYTES);
+        hipError_t e = set_lds(once, kern, LC::LDS_BYTES);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3((g.rows + LC::L - 1) / LC::L, nb), dim3(LC::THREADS), LC::LDS_BYTES, st, ld, T,
                            tw, g);
@@ -669,41 +732,44 @@ struct SizeImpl {
     static hipError_t xpass_real_fwd(const RealImageLoader& ld, float2* T, const float2* tw, const PassGeom& g,
                                      hipStream_t st)
     {
+        static LdsOnce once;
         auto kern = k_xpass<LOG2N, -1, RealImageLoader>;
-        hipError_t e = set_lds(kern, LC::LDS_BYTES);
+        hipError_t e = set_lds(once, kern, LC::LDS_BYTES);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3((g.rows + LC::L - 1) / LC::L, 1), dim3(LC::THREADS), LC::LDS_BYTES, st, ld, T, tw,
                            g);
         return hipGetLastError();
     }
     template <int RL, bool PRUNED>
-    static hipError_t ya(const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb, int G,
-                         hipStream_t st)
+    static hipError_t ya(const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb, int planes, int G,
+                         int gstride, hipStream_t st)
     {
+        static LdsOnce once;
         auto kern = k_ypass_acc<LOG2N, RL, PRUNED>;
-        hipError_t e = set_lds(kern, LC::LDS_BYTES);
+        hipError_t e = set_lds(once, kern, LC::LDS_BYTES);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((g.nt + LC::L - 1) / LC::L, G), dim3(LC::THREADS), LC::LDS_BYTES, st, T, slab, tw,
-                           g, nb, G);
+        hipLaunchKernelGGL(kern, dim3((g.nt + LC::L - 1) / LC::L, planes * G), dim3(LC::THREADS), LC::LDS_BYTES, st, T,
+                           slab, tw, g, nb, G, gstride);
         return hipGetLastError();
     }
     static hipError_t ypass_acc(int variant, const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb,
-                                int G, hipStream_t st)
+                                int planes, int G, int gstride, hipStream_t st)
     {
         switch (variant) {
-            case 0: return ya<0, true>(T, slab, tw, g, nb, G, st);
-            case 1: return ya<1, true>(T, slab, tw, g, nb, G, st);
-            case 2: return ya<2, true>(T, slab, tw, g, nb, G, st);
-            default: return ya<-1, false>(T, slab, tw, g, nb, G, st);
+            case 0: return ya<0, true>(T, slab, tw, g, nb, planes, G, gstride, st);
+            case 1: return ya<1, true>(T, slab, tw, g, nb, planes, G, gstride, st);
+            case 2: return ya<2, true>(T, slab, tw, g, nb, planes, G, gstride, st);
+            default: return ya<-1, false>(T, slab, tw, g, nb, planes, G, gstride, st);
         }
     }
     static hipError_t xpass_w64(const float2* P, const float2* M, const int* shifts, float2* T, const float2* tw,
                                 const PassGeom& g, int nb, hipStream_t st)
     {
         if constexpr (LOG2N == 12) {
+            static LdsOnce once;
             constexpr size_t lds = 4 * Wave4096::LDS_FLOATS * sizeof(float);
             auto kern = k_xpass_w64<LOG2N>;
-            hipError_t e = set_lds(kern, lds);
+            hipError_t e = set_lds(once, kern, lds);
             if (e != hipSuccess) return e;
             const int items = ((g.rows + 3) / 4) * nb;
             const int wgs = items < 512 ? items : 512;               // 256 CUs x 2 resident workgroups
@@ -714,16 +780,17 @@ struct SizeImpl {
             return hipErrorNotSupported;
         }
     }
-    static hipError_t ypass_w64(const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb, int G,
-                                hipStream_t st)
+    static hipError_t ypass_w64(const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb, int planes,
+                                int G, int gstride, hipStream_t st)
     {
         if constexpr (LOG2N >= 10 && LOG2N <= 13) {
+            static LdsOnce once;
             using WS = WaveShape<LOG2N>;
             auto kern = k_ypass_wave<LOG2N>;
-            hipError_t e = set_lds(kern, WS::LDS_BYTES);
+            hipError_t e = set_lds(once, kern, WS::LDS_BYTES);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, dim3((g.nt + WS::TILES - 1) / WS::TILES, G), dim3(WS::THREADS), WS::LDS_BYTES, st, T,
-                               slab, tw, g, nb, G);
+            hipLaunchKernelGGL(kern, dim3((g.nt + WS::TILES - 1) / WS::TILES, planes * G), dim3(WS::THREADS),
+                               WS::LDS_BYTES, st, T, slab, tw, g, nb, G, gstride);
             return hipGetLastError();
         } else {
             return hipErrorNotSupported;
@@ -734,13 +801,15 @@ struct SizeImpl {
     {
         dim3 grid((g.nt + LC::L - 1) / LC::L);
         if (sign > 0) {
+            static LdsOnce once;
             auto kern = k_ypass_field<LOG2N, +1>;
-            hipError_t e = set_lds(kern, LC::LDS_BYTES);
+            hipError_t e = set_lds(once, kern, LC::LDS_BYTES);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(kern, grid, dim3(LC::THREADS), LC::LDS_BYTES, st, T, field, tw, g);
         } else {
+            static LdsOnce once;
             auto kern = k_ypass_field<LOG2N, -1>;
-            hipError_t e = set_lds(kern, LC::LDS_BYTES);
+            hipError_t e = set_lds(once, kern, LC::LDS_BYTES);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(kern, grid, dim3(LC::THREADS), LC::LDS_BYTES, st, T, field, tw, g);
         }

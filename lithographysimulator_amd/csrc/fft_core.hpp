@@ -14,6 +14,17 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// Timing-diagnostic switches (LITHO_DIAG_*) remove loads, stores, barriers or LDS traffic from the kernels and
+// therefore give WRONG RESULTS.  They compile only in a diagnostic build: scripts/build_variants.sh defines
+// LITHO_DIAG_BUILD, writes build/variants/lib_<name>.so (never the product path) and that library reports
+// litho_target_arch() == "gfx950-diag", which the Python binding and __graft_entry__.build() refuse.
+#if (defined(LITHO_DIAG_NOBARRIER) || defined(LITHO_DIAG_NOLDSWRITE) || defined(LITHO_DIAG_NOLDSREAD) ||   \
+     defined(LITHO_DIAG_XNOLOAD) || defined(LITHO_DIAG_XNOSTORE) || defined(LITHO_DIAG_XSTORE_L2) ||       \
+     defined(LITHO_DIAG_YNOLOAD)) &&                                                                       \
+    !defined(LITHO_DIAG_BUILD)
+#error "LITHO_DIAG_* switches produce wrong results; use scripts/build_variants.sh (defines LITHO_DIAG_BUILD, separate output)"
+#endif
+
 namespace litho {
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {

@@ -9,6 +9,17 @@ from .lightsource import sourceShifts
 from .mask import Mask          # the reference forgets this import at module level
 
 
+class ShapeError(ValueError, RuntimeError):
+    """Operand shapes that do not fit together.  The reference dies with a broadcasting RuntimeError at
+    `pf * maskFFFT` (imageformation.py:34) in these cases; a raw device pointer must never see them."""
+
+
+def _square(t, what):
+    if t.dim() != 2 or t.shape[0] != t.shape[1]:
+        raise ShapeError(f"{what} must be a square 2-D tensor; got {tuple(t.shape)}")
+    return int(t.shape[0])
+
+
 def calculateAerial(pupil, maskFT, fraunhoferConstant, pixelNumber, pixelSize, device):
     """imageformation.py:3-30: the O(pn^4) direct integral is outside the engine's scope."""
     raise NotImplementedError("the direct (non-FFT) aerial-image integral is not part of the MI355X engine; "
@@ -17,8 +28,11 @@ def calculateAerial(pupil, maskFT, fraunhoferConstant, pixelNumber, pixelSize, d
 
 def calculateFFTAerial(pf, maskFFFT, pixelNumber, N):
     """imageformation.py:32-45: complex64 [pn,pn] field of one (already rolled) pupil."""
-    dev = nat.require_gpu(maskFFFT.device)
     pn = int(pixelNumber)
+    if _square(maskFFFT, "maskFFFT") != pn or tuple(pf.shape) != (pn, pn):
+        raise ShapeError(f"calculateFFTAerial: pf {tuple(pf.shape)} and maskFFFT {tuple(maskFFFT.shape)} must both be "
+                         f"[{pn},{pn}] (pixelNumber)")
+    dev = nat.require_gpu(maskFFFT.device)
     pf = pf.to(device=dev, dtype=torch.complex64).contiguous()
     m = maskFFFT.to(torch.complex64).contiguous()
     out = torch.empty((pn, pn), dtype=torch.complex64, device=dev)
@@ -35,15 +49,26 @@ def abbeIntensity(maskFT, pupilF, shifts, N, out=None):
     """The loop of abbeImage (imageformation.py:54-67) for an explicit (dy,dx) list:
     returns / accumulates into the raw fp32 intensity [planes?,pn,pn] BEFORE post-processing.
     pupilF may be [pn,pn] or a through-focus stack [planes,pn,pn]."""
+    pn = _square(maskFT, "maskFT")
+    if pupilF.dim() not in (2, 3) or tuple(pupilF.shape[-2:]) != (pn, pn) or (pupilF.dim() == 3 and pupilF.shape[0] < 1):
+        # e.g. a default Pupil() (pixelNumber 64) with a 256^2 mask: the reference fails at pf * maskFFFT
+        raise ShapeError(f"pupilF must be [{pn},{pn}] or [planes,{pn},{pn}] to match maskFT; got {tuple(pupilF.shape)} "
+                         "(build the Pupil with mask.pixelNumber)")
+    if shifts.dim() != 2 or shifts.shape[1] != 2:
+        raise ShapeError(f"shifts must be [S,2] (dy,dx) pairs; got {tuple(shifts.shape)}")
     dev = nat.require_gpu(maskFT.device)
-    pn = maskFT.size()[0]
     m = maskFT.to(torch.complex64).contiguous()
     p = pupilF.to(device=dev, dtype=torch.complex64).contiguous()
     stacked = p.dim() == 3
     planes = p.shape[0] if stacked else 1
     sh = shifts.to(device=dev, dtype=torch.int32).contiguous()
+    want = (planes, pn, pn) if stacked else (pn, pn)
     if out is None:
-        out = torch.zeros((planes, pn, pn) if stacked else (pn, pn), dtype=torch.float32, device=dev)
+        out = torch.zeros(want, dtype=torch.float32, device=dev)
+    elif (out.dtype != torch.float32 or not out.is_contiguous() or out.device != m.device
+          or tuple(out.shape) != want):
+        raise ShapeError(f"out must be a contiguous float32 tensor of shape {want} on {m.device}; got "
+                         f"{out.dtype} {tuple(out.shape)} on {out.device}, contiguous={out.is_contiguous()}")
     rc = nat.lib().litho_abbe_workspace_bytes(pn, int(N), ctypes.byref(ctypes.c_size_t(0)))
     nat.check(rc, "abbeImage")
     ws = nat.workspace(dev, pn, int(N))
@@ -71,30 +96,56 @@ def postProcess(raw, epsilon):
     return out
 
 
+def _all_reduce_sum(image, group):
+    """ONE collective per image/stack (SURVEY 8e).  RCCL ("nccl" backend on ROCm) reduces the device tensor in
+    place over xGMI; a gloo group (CPU tests, or several ranks sharing one GPU) goes through a host copy."""
+    import torch.distributed as dist
+    if dist.get_backend(group) == "gloo" and image.is_cuda:
+        host = image.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        image.copy_(host)
+    else:
+        dist.all_reduce(image, op=dist.ReduceOp.SUM, group=group)
+    return image
+
+
 def abbeImage(mask, maskFT: torch.Tensor, pupilF: torch.Tensor, lightsource: torch.Tensor, pixelSize: int,
-              deltaK: float, wavelength, fft: bool, device: torch.device, group=None):
-    """Drop-in for imageformation.py:47-77.
+              deltaK: float, wavelength, fft: bool, device: torch.device, group=None, normalize: bool = False):
+    """Drop-in for imageformation.py:47-77.  `pupilF` may also be a through-focus stack [planes,pn,pn] (BASELINE
+    config 5; the reference's counterpart is a Python loop over Pupil(...) + abbeImage(...)), in which case the
+    result is [planes,pn',pn'].
 
     `group`: optional torch.distributed process group.  When given (or when a default group
     is initialised and LITHO_SHARD_SOURCES=1), the source-point list is split into contiguous
     shards, one per rank, and the partial intensities are summed with ONE all-reduce (RCCL
-    over xGMI on MI355X) before the linear post-process."""
+    over xGMI on MI355X) before the linear post-process (SURVEY 8e).
+
+    `normalize`: divide by the number of source points S (SURVEY 8f #3; the reference returns raw sums, Q7)."""
     if not fft:
         raise NotImplementedError("only the FFT formulation (fft=True) is built; the direct integral "
                                   "(imageformation.py:3-30) is outside the hot path")
     epsilon, N = Mask.calculateEpsilonN(self=mask, deltaK=deltaK, pixelSize=pixelSize, wavelength=wavelength)
-    pixelNumber = maskFT.size()[0]
+    pixelNumber = _square(maskFT, "maskFT")                                 # imageformation.py:54
+    if pupilF.dim() not in (2, 3) or tuple(pupilF.shape[-2:]) != (pixelNumber, pixelNumber):
+        raise ShapeError(f"pupilF must be [{pixelNumber},{pixelNumber}] or [planes,{pixelNumber},{pixelNumber}] to "
+                         f"match maskFT; got {tuple(pupilF.shape)} (build the Pupil with mask.pixelNumber)")
+    if tuple(lightsource.shape) != (pixelNumber, pixelNumber):
+        # SURVEY Q4: the reference silently mis-shifts when the source grid differs from the mask's
+        raise ShapeError(f"the source bitmap must be [{pixelNumber},{pixelNumber}] (the mask's pixelNumber); got "
+                         f"{tuple(lightsource.shape)}")
     dev = nat.require_gpu(device)
     maskFT = maskFT.to(dev)
     shifts = sourceShifts(lightsource.to(dev), pixelNumber)                # imageformation.py:59
+    total = shifts.shape[0]
     from .distributed import resolve_group, shard_bounds
     group = resolve_group(group)
     if group is not None:
         import torch.distributed as dist
-        lo, hi = shard_bounds(shifts.shape[0], dist.get_rank(group), dist.get_world_size(group))
+        lo, hi = shard_bounds(total, dist.get_rank(group), dist.get_world_size(group))
         shifts = shifts[lo:hi]
     image = abbeIntensity(maskFT, pupilF.to(dev), shifts, N)               # imageformation.py:62-67
     if group is not None:
-        import torch.distributed as dist
-        dist.all_reduce(image, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce_sum(image, group)
+    if normalize and total > 0:
+        image /= float(total)
     return postProcess(image, epsilon)                                      # imageformation.py:69-77

@@ -1,14 +1,21 @@
 #!/bin/bash
 # A/B builds of one FFT size: each variant relinks the library with inst_$L2 rebuilt under other flags.
 #   scripts/build_variants.sh 12 name1 "flags1" name2 "flags2" ...
+# Output: build/variants/lib_<name>.so (never the product path).  Flags containing LITHO_DIAG_ give a
+# diagnostic build (wrong results, timing only): LITHO_DIAG_BUILD is added and the library reports
+# litho_target_arch() == "gfx950-diag" so that the binding refuses it unless LITHO_ALLOW_DIAG=1.
 set -e
 cd "$(dirname "$0")/.."
 L2=$1; shift
 mkdir -p build/variants
-OBJS="build/abbe_engine.o build/optics.o build/common.o $(ls build/inst_*.o | grep -v inst_$L2)"
+BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC"
+OBJS="build/abbe_engine.o build/optics.o $(ls build/inst_*.o | grep -v inst_$L2)"
+hipcc $BASE -DLITHO_DIAG_BUILD -c lithographysimulator_amd/csrc/common.hip -o build/variants/common_diag.o
 build() {
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-signed-zeros -fno-slp-vectorize $2 -c lithographysimulator_amd/csrc/inst_$L2.hip -o build/variants/inst_${L2}_$1.o
-  hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/lib_$1.so $OBJS build/variants/inst_${L2}_$1.o
+  local extra="" common="build/common.o"
+  case "$2" in *LITHO_DIAG_*) extra="-DLITHO_DIAG_BUILD"; common="build/variants/common_diag.o";; esac
+  hipcc $BASE -fno-signed-zeros -fno-slp-vectorize $extra $2 -c lithographysimulator_amd/csrc/inst_$L2.hip -o build/variants/inst_${L2}_$1.o
+  hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/lib_$1.so $OBJS $common build/variants/inst_${L2}_$1.o
 }
 while [ $# -gt 0 ]; do build "$1" "$2" & shift 2; done
 wait

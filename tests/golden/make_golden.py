@@ -327,9 +327,43 @@ def g8_large_pupils():
     save("g8_large_pupils.npz", **out)
 
 
+def g9_config5_stack():
+    """BASELINE config 5 AT ITS SIZE: 2048^2, 32 through-focus planes (aberrations[4] = -310 + 20 k nm, the other
+    terms = the demo vector), K = 3 source points strided through the quasar list.  The reference has no stack
+    API: this is its Python loop over Pupil(...) + abbeImage(...) (imageformation.py:47-77, pupil.py:91-92).
+    Per plane: centre crop, fp64 row / column sums, max and sum of the raw intensity and of the final image."""
+    print("G9 config-5 stack (2048^2 x 32 planes)")
+    pn, K = 2048, 3
+    out = {}
+    defocus = [-310 + 20 * k for k in range(32)]
+    out["defocus_nm"] = np.array(defocus, dtype=np.float64)
+    mk = quiet(ref_mask.Mask, bernoulli_mask(pn), PS, CPU)
+    mft = mk.fraunhofer(WL, True)
+    eps, N = mk.calculateEpsilonN(mk.deltaK, PS, WL)
+    bm = subsample_bitmap(source("quasar", pn, 0.4, 0.8), K)
+    out["shifts"] = shifts_of(bm, pn)
+    keys = ("crop", "rowsum", "colsum", "max", "sum")
+    acc = {f"{kind}_{k}": [] for kind in ("raw", "final") for k in keys}
+    for i, d in enumerate(defocus):
+        ab = list(DEMO_AB); ab[4] = d
+        pf = pupil_fn(pn, ab)
+        tmp = {}
+        crop_stats("raw", raw_image(mft, pf, bm, N), tmp, crop=64)
+        crop_stats("final", ref_if.abbeImage(mk, mft, pf, bm, PS, mk.deltaK, WL, True, CPU), tmp, crop=64)
+        for kind in ("raw", "final"):
+            for k in keys:
+                v = tmp[f"{kind}_{k}"]
+                acc[f"{kind}_{k}"].append(v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+        print(f"   plane {i:2d} d={d:5d} nm  raw sum {float(tmp['raw_sum']):.6e}", flush=True)
+    for k, v in acc.items():
+        out[k] = np.stack(v)
+    out["final_shape"] = tmp["final_shape"]
+    save("g9_config5_stack.npz", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9"]
     for g in which:
         {"g1": g1_sources, "g2": g2_pupils, "g3": g3_mask_spectra, "g4": g4_fields,
-         "g5": g5_images, "g6": g6_through_focus, "g8": g8_large_pupils}[g]()
+         "g5": g5_images, "g6": g6_through_focus, "g8": g8_large_pupils, "g9": g9_config5_stack}[g]()

@@ -228,6 +228,74 @@ def test_through_focus_demo_planes(golden, L, dev):
         assert rel_max(img, g["stack64_final"][k]) < TOL_IMAGE_MAX
 
 
+def test_config5_stack_at_size_vs_golden(golden, L, dev):
+    """BASELINE config 5 AT ITS SIZE: 2048^2 x 32 through-focus planes (d_k = -310 + 20 k nm), K = 3 strided quasar
+    points, against the reference's own loop over Pupil(...) + abbeImage(...) (golden g9).  The stack goes through
+    the plane-fused x-pass (mask-spectrum window gathered once per source point for the planes in flight)."""
+    from lithographysimulator_amd import _native as nat
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    g = golden("g9_config5_stack.npz")
+    pn = 2048
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    defocus = [float(d) for d in g["defocus_nm"]]
+    assert len(defocus) == 32
+    stack = L.throughFocusPupils(pn, WL, NA, f16(DEMO_AB), defocus, dev)
+    shifts = torch.from_numpy(g["shifts"]).to(dev)
+    raw = L.abbeIntensity(mft, stack, shifts, N)
+    plan = nat.last_plan()
+    assert plan["fused_xpass"] == 1 and plan["planes_in_flight"] == 4 and plan["variant"] == 1
+    assert raw.shape == (32, pn, pn)
+    img = L.postProcess(raw, eps)
+    assert tuple(img.shape[1:]) == tuple(g["final_shape"])
+    raw, img = raw.cpu(), img.cpu()
+    worst = 0.0
+    for k in range(32):
+        for got, kind in ((raw[k], "raw"), (img[k], "final")):
+            crop = crop_center(got, 64)
+            e = float((crop.double() - torch.from_numpy(g[f"{kind}_crop"][k]).double()).abs().max() / g[f"{kind}_max"][k])
+            worst = max(worst, e)
+            assert e < TOL_IMAGE_MAX, (k, kind, e)
+            assert np.allclose(got.double().sum(1).numpy(), g[f"{kind}_rowsum"][k], rtol=2e-5), (k, kind)
+            assert np.allclose(got.double().sum(0).numpy(), g[f"{kind}_colsum"][k], rtol=2e-5), (k, kind)
+            assert abs(float(got.max()) / float(g[f"{kind}_max"][k]) - 1) < 2e-5, (k, kind)
+    print(f"config-5 stack: worst crop error rel-to-max {worst:.2e}")
+    # plane p of the fused stack == the single-plane call (the round-1 plane-by-plane path), every chunk position
+    for k in (0, 5, 18, 31):
+        one = L.abbeIntensity(mft, stack[k], shifts, N).cpu()
+        assert rel_max(raw[k], one) < 1e-6, k
+    # stacks that are not a multiple of 4 planes (NP = 2 and NP = 1 launches) and the plane-chunk knob
+    part = L.abbeIntensity(mft, stack[4:11], shifts, N).cpu()
+    for j in range(7):
+        assert rel_max(part[j], raw[4 + j]) < 1e-6, j
+
+
+def test_stack_plane_chunk_knob_and_generic_variant(L, dev, monkeypatch):
+    """Through-focus stacks through the non-fused x-pass variants (generic kernels, general/wrapping path) and with
+    other plane-chunk sizes must agree with the fused default."""
+    from lithographysimulator_amd import _native as nat
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    pn = 512
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    stack = L.throughFocusPupils(pn, WL, NA, f16(DEMO_AB), [-200.0, -90.0, 0.0, 70.0, 130.0, 310.0], dev)
+    sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateAnnular(), pn)
+    sel = sh[(torch.arange(37, device=dev) * sh.shape[0]) // 37]
+    ref = L.abbeIntensity(mft, stack, sel, N).cpu()
+    assert nat.last_plan()["fused_xpass"] == 1
+    for env in ({"LITHO_ABBE_PLANE_CHUNK": "1"}, {"LITHO_ABBE_PLANE_CHUNK": "2"}, {"LITHO_ABBE_PLANE_CHUNK": "3"},
+                {"LITHO_ABBE_PLANE_CHUNK": "6"}, {"LITHO_ABBE_FORCE_GENERIC": "1"}, {"LITHO_ABBE_FORCE_GENERAL": "1"},
+                {"LITHO_ABBE_W64": "0"}, {"LITHO_ABBE_BATCH": "5", "LITHO_ABBE_XCHUNK": "2"}):
+        got = _with_env(monkeypatch, L, env, lambda: L.abbeIntensity(mft, stack, sel, N).cpu())
+        for k in range(6):
+            assert rel_max(got[k], ref[k]) < 2e-6, (env, k)
+    o = O()
+    chain = o.abbe_raw(mft.cpu(), stack[3].cpu(), sel.cpu(), N)
+    assert rel_max(ref[3], chain) < TOL_IMAGE_MAX
+
+
 # ------------------------------------------------------------------ size-independent properties at full size
 def test_properties_2048(L, dev):
     """At BASELINE config 3's full grid (2048^2, N = 4096): the Abbe sum is additive over any

@@ -1,7 +1,8 @@
 """The RCCL leg of the path on the GPU box: abbeImage(..., group=...) with backend "nccl" (= RCCL on ROCm).
-Only one GPU is available to the tests, so the group has one rank; the code path (shard bounds, accumulate on
-the shard, all_reduce over RCCL, post-process) is the one bench.py --gpus N uses.  World-size-2 behaviour of
-the sharding arithmetic is covered on CPU with gloo (tests/test_distributed_cpu.py)."""
+Only one GPU is available to the tests, so the RCCL group has one rank; the code path (shard bounds, accumulate on
+the shard, all_reduce over RCCL, post-process) is the one bench.py --gpus N uses.  The world-size-2 behaviour of
+that same path with the real kernels is exercised by two ranks SHARING cuda:0 over gloo (second test), and on CPU
+with oracle stand-ins (tests/test_distributed_cpu.py)."""
 import os
 import subprocess
 import sys
@@ -13,10 +14,17 @@ from helpers import ROOT
 
 pytestmark = pytest.mark.gpu
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 SCRIPT = textwrap.dedent("""
     import math, os, sys, torch, torch.distributed as dist
     sys.path.insert(0, %r)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+    os.environ.update(MASTER_ADDR="127.0.0.1", RANK="0", WORLD_SIZE="1")
     dev = torch.device("cuda", 0)
     dist.init_process_group("nccl", device_id=dev)
     import lithographysimulator_amd as L
@@ -35,8 +43,70 @@ SCRIPT = textwrap.dedent("""
 
 
 def test_rccl_group_path_single_rank():
-    out = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    out = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                         env=dict(os.environ, MASTER_PORT=str(_free_port())))
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0].split()
     assert float(line[1]) == 0.0 and float(line[2]) == 0.0
     assert abs(float(line[3]) / 2.2029254e13 - 1) < 1e-5            # the reference's demo image sum
+
+
+# Two FRESH processes (started before anything here touches the GPU), both on cuda:0, gloo rendezvous: the product's
+# abbeImage(group=WORLD) = shard -> HIP accumulate on the shard -> ONE all-reduce -> post-process, world_size 2.
+# (RCCL refuses two ranks on one device, so the collective of this test is gloo's; the 8-GPU run uses "nccl".)
+TWO_RANK = textwrap.dedent("""
+    import math, os, sys, torch, torch.distributed as dist
+    sys.path.insert(0, %r)
+    rank = int(os.environ["RANK"])
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    dev = torch.device("cuda", 0)
+    import lithographysimulator_amd as L
+    from lithographysimulator_amd import _native as nat
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    W = dist.group.WORLD
+    res = {}
+    # (a) BASELINE config 1 end to end: 256^2, S = 3233 (odd: shards of 1617 and 1616)
+    m = L.Mask(bernoulli_mask(256), 25, dev); mft = m.fraunhofer(193., True)
+    bm = L.LightSource(0.0, 0.5, 256, 0.7, device=dev).generateAnnular()
+    pf = L.Pupil(256, 193., 0.7, None, dev).generatePupilFunction()
+    sharded = L.abbeImage(m, mft, pf, bm, 25, m.deltaK, 193., True, dev, group=W)
+    whole = L.abbeImage(m, mft, pf, bm, 25, m.deltaK, 193., True, dev)
+    res["a"] = float((sharded - whole).abs().max() / whole.max())
+    # (b) S = 1 < world: the last rank's shard is empty
+    one = torch.zeros_like(bm); one[140, 120] = 1
+    s1 = L.abbeImage(m, mft, pf, one, 25, m.deltaK, 193., True, dev, group=W)
+    w1 = L.abbeImage(m, mft, pf, one, 25, m.deltaK, 193., True, dev)
+    res["b"] = float((s1 - w1).abs().max() / w1.max())
+    # (c) a 3-plane through-focus stack at 1024^2 (fused x-pass), 22 strided annular points, rank-dependent shard sizes
+    m2 = L.Mask(bernoulli_mask(1024), 25, dev); mft2 = m2.fraunhofer(193., True)
+    ab = torch.tensor([0, 0, 0.01, 0, 100, 0.01, 0, 0.01, 0.01, 0.01], dtype=torch.float16)
+    stack = L.throughFocusPupils(1024, 193., 0.7, ab, [-110.0, 10.0, 90.0], dev)
+    full = L.LightSource(0.4, 0.8, 1024, 0.7, device=dev).generateAnnular()
+    pts = torch.argwhere(full); idx = (torch.arange(21, device=dev) * pts.shape[0]) // 21
+    sub = torch.zeros_like(full); sub[pts[idx, 0], pts[idx, 1]] = 1
+    s3 = L.abbeImage(m2, mft2, stack, sub, 25, m2.deltaK, 193., True, dev, group=W)
+    w3 = L.abbeImage(m2, mft2, stack, sub, 25, m2.deltaK, 193., True, dev)
+    res["c"] = float((s3 - w3).abs().max() / w3.max()); res["c_shape"] = list(s3.shape)
+    torch.cuda.synchronize()
+    print("RESULT", rank, res["a"], res["b"], res["c"], res["c_shape"], float(whole.double().sum()))
+    dist.barrier()
+    dist.destroy_process_group()
+""") % ROOT
+
+
+def test_two_ranks_share_one_gpu_over_gloo(golden):
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, "-c", TWO_RANK], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              cwd=ROOT, env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                                                 RANK=str(r), WORLD_SIZE="2"))
+             for r in range(2)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    ref_sum = float(golden("g5_images.npz")["cfg1_bern_final"].astype("float64").sum())
+    for so, _ in outs:
+        f = [l for l in so.splitlines() if l.startswith("RESULT")][0].split(maxsplit=5)
+        a, b, c = float(f[2]), float(f[3]), float(f[4])
+        assert a < 2e-6 and b < 2e-6 and c < 2e-6, (a, b, c)
+        assert "[3, 1024, 1024]" in f[5]
+        assert abs(float(f[5].split("]")[1]) / ref_sum - 1) < 1e-5          # and it is the reference's config-1 image

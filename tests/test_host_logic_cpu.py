@@ -48,6 +48,32 @@ def test_no_cpu_fallback():
         L.abbeImage(m, z, z, torch.zeros(64, 64, dtype=torch.int64), 25, m.deltaK, WL, True, CPU)
 
 
+def test_mismatched_shapes_are_rejected_before_any_pointer_is_taken():
+    """A default Pupil()/LightSource() is 64^2 (pupil.py:6, lightsource.py:5); with a 256^2 mask the reference dies
+    with a broadcasting RuntimeError at imageformation.py:34.  Here the same call must raise (ValueError and
+    RuntimeError both match) instead of handing a 64^2 buffer to kernels sized for 256^2."""
+    from lithographysimulator_amd.imageformation import ShapeError
+    m256 = torch.zeros(256, 256, dtype=torch.complex64)
+    p64 = torch.zeros(64, 64, dtype=torch.complex64)
+    sh = torch.zeros(3, 2, dtype=torch.int32)
+    for exc in (ShapeError, ValueError, RuntimeError):
+        with pytest.raises(exc, match="pupilF must be"):
+            L.abbeIntensity(m256, p64, sh, 512)
+    with pytest.raises(ShapeError, match="pupilF must be"):
+        L.abbeIntensity(m256, torch.zeros(2, 64, 64, dtype=torch.complex64), sh, 512)
+    with pytest.raises(ShapeError, match="square"):
+        L.abbeIntensity(torch.zeros(256, 128, dtype=torch.complex64), p64, sh, 512)
+    with pytest.raises(ShapeError, match="shifts must be"):
+        L.abbeIntensity(m256, m256, torch.zeros(6, dtype=torch.int32), 512)
+    with pytest.raises(ShapeError, match="calculateFFTAerial"):
+        L.calculateFFTAerial(p64, m256, 256, 512)
+    with pytest.raises(ShapeError, match="calculateFFTAerial"):
+        L.calculateFFTAerial(m256, m256, 64, 128)
+    mask = L.Mask(bernoulli_mask(256), 25, CPU)
+    with pytest.raises(ValueError):            # source bitmap of the wrong size (SURVEY Q4) or wrong pupil
+        L.abbeImage(mask, m256, p64, torch.zeros(256, 256, dtype=torch.int64), 25, mask.deltaK, WL, True, CPU)
+
+
 def test_direct_solver_is_declared_out_of_scope():
     m = L.Mask(bernoulli_mask(64), 25, CPU)
     with pytest.raises(NotImplementedError):

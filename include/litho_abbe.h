@@ -55,7 +55,9 @@ int litho_source_bitmap(int kind, double sigma_in, double sigma_out, int pn,
 /* ---- imageformation.py:59 `(argwhere(lightsource) - pn//2).int()`: compacts any int64
  * bitmap [pn,pn] (non-zero = lit) into int32 [S,2] (dy,dx) in row-major order.
  * `shifts` must have room for pn*pn pairs (or `capacity` pairs; more lit pixels than
- * that is LITHO_E_ARG).  Reads back: *count_host = S.  scratch: (pn+1) int32. */
+ * that is LITHO_E_ARG).  scratch: (pn+1) int32.  Reads back: *count_host = S.
+ * Asynchronous form: count_host == NULL -- nothing is read back and the call does not wait; S stays on the
+ * device in scratch[pn] (an int32) for litho_abbe_accumulate_counted. */
 int litho_source_compact(const int64_t *bitmap, int pn, int32_t *shifts, int64_t capacity,
                          int32_t *scratch, int64_t *count_host, void *stream);
 
@@ -65,8 +67,9 @@ int litho_source_compact(const int64_t *bitmap, int pn, int32_t *shifts, int64_t
  * rescaled vector is written back to coeffs_f16_host (the reference mutates its
  * argument).  flags bit 0: skip that rescale (single-term generateZ,
  * pupil.py:46-77).  Outputs (either may be NULL): wavefront = fp16 W [pn,pn] as uint16
- * bit patterns, pupil = complex64 phi [pn,pn].  Waits for `stream` before returning
- * (the term table is staged from host memory). */
+ * bit patterns, pupil = complex64 phi [pn,pn].  Asynchronous for J <= 32 (the term table
+ * travels in the kernel arguments); longer vectors are staged through a transient device
+ * buffer and the call waits for `stream`. */
 int litho_pupil(uint16_t *coeffs_f16_host, int J, int pn, double NA, double wavelength, int flags,
                 uint16_t *wavefront, void *pupil, void *stream);
 
@@ -83,10 +86,19 @@ int litho_abbe_workspace_bytes(int pn, int N, size_t *bytes_host);
  * stack sharing maskFT and the source list); shifts int32 [S,2] = (dy,dx) =
  * (row - pn/2, col - pn/2); out fp32 [planes,pn,pn], accumulated into (the caller zeroes
  * it, and all-reduces it across GPUs when the source list is sharded).
- * Reads back 32 bytes once (pupil support box and shift extents) to plan the launch. */
+ * Reads back 36 bytes once (pupil support box, shift extents, count) to plan the launch. */
 int litho_abbe_accumulate(const void *maskFT, const void *pupil, int planes,
                           const int32_t *shifts, int64_t S, int pn, int N, float *out,
                           void *workspace, size_t workspace_bytes, void *stream);
+
+/* Same, with the source-point count left ON THE DEVICE by the asynchronous litho_source_compact:
+ * count_dev = &scratch[pn] of that call, capacity = room in `shifts` (the count is clamped to it).  The count
+ * comes back with the planning read-back, so compaction + accumulation + post-process of one image wait for the
+ * stream exactly once.  *count_host (may be NULL) receives S. */
+int litho_abbe_accumulate_counted(const void *maskFT, const void *pupil, int planes,
+                                  const int32_t *shifts, const int32_t *count_dev, int64_t capacity,
+                                  int pn, int N, float *out, void *workspace, size_t workspace_bytes,
+                                  void *stream, int64_t *count_host);
 
 /* ---- Single-point field: calculateFFTAerial(pf, maskFFFT, pixelNumber, N)
  * (imageformation.py:32-45).  field = complex64 [pn,pn].  Reads back 16 bytes. */

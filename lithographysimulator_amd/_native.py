@@ -27,6 +27,8 @@ _SIGNATURES = {
     "litho_abbe_workspace_bytes": (c_int, [c_int, c_int, POINTER(c_size_t)]),
     "litho_abbe_accumulate": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p,
                                       c_void_p, c_size_t, c_void_p]),
+    "litho_abbe_accumulate_counted": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                              c_void_p, c_void_p, c_size_t, c_void_p, POINTER(c_int64)]),
     "litho_abbe_field": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "litho_postprocess_size": (c_int, [c_int, c_double, POINTER(c_int)]),
     "litho_postprocess": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p]),

@@ -93,8 +93,15 @@ __global__ __launch_bounds__(256) void k_pupil_box(const float2* __restrict__ P,
     }
 }
 
-__global__ void k_shift_extents(const int* __restrict__ shifts, long long S, int* plan)
+// S comes from the host, or -- asynchronous image path -- from the device word litho_source_compact left behind
+// (count_dev, clamped to `S` = the capacity); plan[8] returns the count actually used.
+__global__ void k_shift_extents(const int* __restrict__ shifts, long long S, const int* __restrict__ count_dev, int* plan)
 {
+    if (count_dev) {
+        const long long c = *count_dev;
+        S = c < S ? c : S;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) plan[8] = (int)S;
     int ymin = INT_MAX, ymax = INT_MIN, xmin = INT_MAX, xmax = INT_MIN;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (long long)gridDim.x * blockDim.x) {
         const int dy = shifts[2 * i], dx = shifts[2 * i + 1];
@@ -258,10 +265,10 @@ static int pick_variant(const PassGeom& g, const Knobs& kn)
     return kn.force_generic ? -1 : rl;
 }
 
-// Reads the 8 plan words back (one small synchronising copy).
-static int read_plan(const Workspace& w, int host[8], hipStream_t st)
+// Reads the 9 plan words back (one small synchronising copy).
+static int read_plan(const Workspace& w, int host[9], hipStream_t st)
 {
-    HIP_TRY(hipMemcpyAsync(host, w.plan, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(host, w.plan, 9 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return LITHO_OK;
 }
@@ -319,11 +326,13 @@ struct MarkList {
 };
 
 static int abbe_accumulate(const float2* M, const float2* P, int planes, const int* shifts, int64_t S,
-                           int pn, int N, float* out, void* ws, size_t ws_bytes, hipStream_t st)
+                           const int* count_dev, int64_t* count_out, int pn, int N, float* out, void* ws,
+                           size_t ws_bytes, hipStream_t st)
 {
     int rc = check_sizes(pn, N);
     if (rc) return rc;
     if (!M || !P || !out || planes < 1 || S < 0 || (S > 0 && !shifts)) return LITHO_E_ARG;
+    if (count_out) *count_out = 0;
     if (S == 0) return LITHO_OK;
     Workspace w;
     if (!carve(ws, ws_bytes, pn, N, w)) return LITHO_E_WORKSPACE;
@@ -333,12 +342,14 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     hipLaunchKernelGGL(k_plan_init, dim3(1), dim3(64), 0, st, w.plan);
     hipLaunchKernelGGL(k_pupil_box, dim3((pn + BOX_ROWS_PER_BLOCK - 1) / BOX_ROWS_PER_BLOCK, planes), dim3(256), 0, st,
                        P, pn, w.plan);
-    hipLaunchKernelGGL(k_shift_extents, dim3(256), dim3(256), 0, st, shifts, (long long)S, w.plan);
+    hipLaunchKernelGGL(k_shift_extents, dim3(256), dim3(256), 0, st, shifts, (long long)S, count_dev, w.plan);
     HIP_TRY(hipGetLastError());
-    int pl[8];
-    rc = read_plan(w, pl, st);
+    int pl[9];
+    rc = read_plan(w, pl, st);                               // the ONE host wait of the image path
     if (rc) return rc;
-    if (pl[1] < pl[0]) return LITHO_OK;                      // pupil identically zero: nothing to add
+    S = pl[8];                                               // = S, or the device-side count of the source list
+    if (count_out) *count_out = S;
+    if (S == 0 || pl[1] < pl[0]) return LITHO_OK;            // no source point / pupil identically zero: nothing to add
 
     int r0 = pl[0], h = pl[1] - pl[0] + 1, c0 = pl[2], wdt = pl[3] - pl[2] + 1;
     const bool nowrap = (r0 + pl[4] >= 0) && (r0 + h - 1 + pl[5] <= pn - 1) &&
@@ -485,7 +496,7 @@ static int abbe_field(const float2* pf, const float2* M, int pn, int N, float2* 
     hipLaunchKernelGGL(k_plan_init, dim3(1), dim3(64), 0, st, w.plan);
     hipLaunchKernelGGL(k_pupil_box, dim3((pn + BOX_ROWS_PER_BLOCK - 1) / BOX_ROWS_PER_BLOCK, 1), dim3(256), 0, st, pf, pn, w.plan);
     HIP_TRY(hipGetLastError());
-    int pl[8];
+    int pl[9];
     rc = read_plan(w, pl, st);
     if (rc) return rc;
     if (pl[1] < pl[0]) {                                      // zero pupil -> zero field
@@ -563,8 +574,17 @@ int litho_abbe_workspace_bytes(int pn, int N, size_t* bytes_host)
 int litho_abbe_accumulate(const void* maskFT, const void* pupil, int planes, const int32_t* shifts, int64_t S,
                           int pn, int N, float* out, void* workspace, size_t workspace_bytes, void* stream)
 {
-    return litho::abbe_accumulate((const float2*)maskFT, (const float2*)pupil, planes, shifts, S, pn, N, out,
-                                  workspace, workspace_bytes, (hipStream_t)stream);
+    return litho::abbe_accumulate((const float2*)maskFT, (const float2*)pupil, planes, shifts, S, nullptr, nullptr, pn, N,
+                                  out, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int litho_abbe_accumulate_counted(const void* maskFT, const void* pupil, int planes, const int32_t* shifts,
+                                  const int32_t* count_dev, int64_t capacity, int pn, int N, float* out,
+                                  void* workspace, size_t workspace_bytes, void* stream, int64_t* count_host)
+{
+    if (!count_dev) return LITHO_E_ARG;
+    return litho::abbe_accumulate((const float2*)maskFT, (const float2*)pupil, planes, shifts, capacity, count_dev,
+                                  count_host, pn, N, out, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int litho_abbe_field(const void* pf, const void* maskFT, int pn, int N, void* field, void* workspace,

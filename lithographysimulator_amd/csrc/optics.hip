@@ -140,8 +140,16 @@ __device__ __forceinline__ float pow_int_rn(float r, int p)
     return (float)v;
 }
 
-__global__ void k_pupil(const ZTerm* __restrict__ terms, int J, int pn, float fs, float fst, float twopi_f,
-                        uint16_t* __restrict__ wavefront, float2* __restrict__ pupil)
+// Up to PACK_TERMS Zernike terms travel by value in the kernel-argument segment (no staging copy, no host wait);
+// longer aberration vectors go through a staged device table.
+static constexpr int PACK_TERMS = 32;
+struct ZTermPack {
+    ZTerm t[PACK_TERMS];
+};
+
+template <typename Terms>
+__device__ __forceinline__ void pupil_body(const Terms& terms, int J, int pn, float fs, float fst, float twopi_f,
+                                           uint16_t* __restrict__ wavefront, float2* __restrict__ pupil)
 {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     const int row = blockIdx.y;
@@ -172,6 +180,17 @@ __global__ void k_pupil(const ZTerm* __restrict__ terms, int J, int pn, float fs
         }
         pupil[idx] = phi;
     }
+}
+
+__global__ void k_pupil(const ZTerm* __restrict__ terms, int J, int pn, float fs, float fst, float twopi_f,
+                        uint16_t* __restrict__ wavefront, float2* __restrict__ pupil)
+{
+    pupil_body(terms, J, pn, fs, fst, twopi_f, wavefront, pupil);
+}
+__global__ void k_pupil_packed(const ZTermPack pack, int J, int pn, float fs, float fst, float twopi_f,
+                               uint16_t* __restrict__ wavefront, float2* __restrict__ pupil)
+{
+    pupil_body(pack.t, J, pn, fs, fst, twopi_f, wavefront, pupil);
 }
 
 // generatePhi (pupil.py:102-111) for an arbitrary complex64 WE = a + i b:
@@ -306,12 +325,13 @@ int litho_source_compact(const int64_t* bitmap, int pn, int32_t* shifts, int64_t
                          int64_t* count_host, void* stream)
 {
     using namespace litho;
-    if (!bitmap || !shifts || !scratch || !count_host || pn < 1 || capacity < 0) return LITHO_E_ARG;
+    if (!bitmap || !shifts || !scratch || pn < 1 || capacity < 0) return LITHO_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_row_counts, dim3(pn), dim3(256), 0, st, bitmap, pn, scratch);
     hipLaunchKernelGGL(k_row_scan, dim3(1), dim3(1024), 0, st, scratch, pn);
     hipLaunchKernelGGL(k_row_write, dim3(pn), dim3(64), 0, st, bitmap, pn, scratch, shifts, (long long)capacity);
     HIP_TRY(hipGetLastError());
+    if (!count_host) return LITHO_OK;                // asynchronous form: S stays on the device in scratch[pn]
     int total = 0;
     HIP_TRY(hipMemcpyAsync(&total, scratch + pn, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -351,6 +371,15 @@ int litho_pupil(uint16_t* coeffs_f16_host, int J, int pn, double NA, double wave
         }
         const double Nmn = std::sqrt((2.0 * t.n + 1.0) / (1.0 + (t.m == 0 ? 1.0 : 0.0)));   // pupil.py:68
         t.cN = h16_host(c[j] * (float)(t.m >= 0 ? Nmn : -Nmn));          // pupil.py:71/73
+    }
+    if (J <= PACK_TERMS) {                                               // asynchronous: terms ride in the kernarg segment
+        ZTermPack pack;
+        memset(&pack, 0, sizeof(pack));
+        for (int j = 0; j < J; ++j) pack.t[j] = terms[j];
+        hipLaunchKernelGGL(k_pupil_packed, dim3((pn + 255) / 256, pn), dim3(256), 0, st, pack, J, pn, -2.0f,
+                           (float)(4.0 / pn), (float)(2.0 * M_PI), wavefront, (float2*)pupil);
+        HIP_TRY(hipGetLastError());
+        return LITHO_OK;
     }
     ZTerm* dterms = nullptr;
     HIP_TRY(hipMallocAsync((void**)&dterms, sizeof(ZTerm) * J, st));

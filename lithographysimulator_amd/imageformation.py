@@ -5,7 +5,7 @@ import ctypes
 import torch
 
 from . import _native as nat
-from .lightsource import sourceShifts
+from .lightsource import sourceShifts, sourceShiftsAsync
 from .mask import Mask          # the reference forgets this import at module level
 
 
@@ -45,10 +45,13 @@ def calculateFFTAerial(pf, maskFFFT, pixelNumber, N):
     return out
 
 
-def abbeIntensity(maskFT, pupilF, shifts, N, out=None):
+def abbeIntensity(maskFT, pupilF, shifts, N, out=None, count=None):
     """The loop of abbeImage (imageformation.py:54-67) for an explicit (dy,dx) list:
     returns / accumulates into the raw fp32 intensity [planes?,pn,pn] BEFORE post-processing.
-    pupilF may be [pn,pn] or a through-focus stack [planes,pn,pn]."""
+    pupilF may be [pn,pn] or a through-focus stack [planes,pn,pn].
+    `count`: optional 1-element int32 DEVICE tensor holding the number of valid rows of `shifts`
+    (sourceShiftsAsync); the call then returns (intensity, S) and the whole image path waits for the
+    stream once."""
     pn = _square(maskFT, "maskFT")
     if pupilF.dim() not in (2, 3) or tuple(pupilF.shape[-2:]) != (pn, pn) or (pupilF.dim() == 3 and pupilF.shape[0] < 1):
         # e.g. a default Pupil() (pixelNumber 64) with a 256^2 mask: the reference fails at pf * maskFFFT
@@ -73,6 +76,15 @@ def abbeIntensity(maskFT, pupilF, shifts, N, out=None):
     nat.check(rc, "abbeImage")
     ws = nat.workspace(dev, pn, int(N))
     with torch.cuda.device(dev):
+        if count is not None:
+            if count.dtype != torch.int32 or count.numel() != 1 or count.device != m.device:
+                raise ShapeError("count must be a 1-element int32 tensor on the mask's device")
+            S = ctypes.c_int64(0)
+            nat.check(nat.lib().litho_abbe_accumulate_counted(nat.ptr(m), nat.ptr(p), planes, nat.ptr(sh), nat.ptr(count),
+                                                              sh.shape[0], pn, int(N), nat.ptr(out), nat.ptr(ws),
+                                                              ws.numel(), nat.stream_ptr(dev), ctypes.byref(S)),
+                      "litho_abbe_accumulate_counted")
+            return out, S.value
         nat.check(nat.lib().litho_abbe_accumulate(nat.ptr(m), nat.ptr(p), planes, nat.ptr(sh), sh.shape[0], pn,
                                                   int(N), nat.ptr(out), nat.ptr(ws), ws.numel(),
                                                   nat.stream_ptr(dev)), "litho_abbe_accumulate")
@@ -135,16 +147,18 @@ def abbeImage(mask, maskFT: torch.Tensor, pupilF: torch.Tensor, lightsource: tor
                          f"{tuple(lightsource.shape)}")
     dev = nat.require_gpu(device)
     maskFT = maskFT.to(dev)
-    shifts = sourceShifts(lightsource.to(dev), pixelNumber)                # imageformation.py:59
-    total = shifts.shape[0]
     from .distributed import resolve_group, shard_bounds
     group = resolve_group(group)
-    if group is not None:
+    if group is None:
+        # single GPU: the source count never visits the host on its own -- one stream wait per image
+        shifts, count = sourceShiftsAsync(lightsource.to(dev), pixelNumber)          # imageformation.py:59
+        image, total = abbeIntensity(maskFT, pupilF.to(dev), shifts, N, count=count)  # imageformation.py:62-67
+    else:
         import torch.distributed as dist
+        shifts = sourceShifts(lightsource.to(dev), pixelNumber)            # imageformation.py:59
+        total = shifts.shape[0]
         lo, hi = shard_bounds(total, dist.get_rank(group), dist.get_world_size(group))
-        shifts = shifts[lo:hi]
-    image = abbeIntensity(maskFT, pupilF.to(dev), shifts, N)               # imageformation.py:62-67
-    if group is not None:
+        image = abbeIntensity(maskFT, pupilF.to(dev), shifts[lo:hi], N)    # imageformation.py:62-67
         _all_reduce_sum(image, group)
     if normalize and total > 0:
         image /= float(total)

@@ -40,6 +40,22 @@ class LightSource:
         return self._bitmap(1, count, rotation)
 
 
+def sourceShiftsAsync(lightsource: torch.Tensor, pixelNumber: int):
+    """The same compaction without the host read-back: returns (shifts [pn*pn,2] int32 with only the first S rows
+    written, count = 1-element int32 device tensor holding S).  For abbeIntensity(..., count=...)."""
+    dev = nat.require_gpu(lightsource.device)
+    pn = int(pixelNumber)
+    if lightsource.dim() != 2 or lightsource.shape[0] != pn or lightsource.shape[1] != pn:
+        raise ValueError(f"the source bitmap must be [{pn},{pn}] (the mask's pixelNumber); got {tuple(lightsource.shape)}")
+    bm = lightsource.to(torch.int64).contiguous()
+    shifts = torch.empty((pn * pn, 2), dtype=torch.int32, device=dev)
+    scratch = torch.empty(pn + 1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(nat.lib().litho_source_compact(nat.ptr(bm), pn, nat.ptr(shifts), pn * pn, nat.ptr(scratch), None,
+                                                 nat.stream_ptr(dev)), "litho_source_compact")
+    return shifts, scratch[pn:pn + 1]
+
+
 def sourceShifts(lightsource: torch.Tensor, pixelNumber: int) -> torch.Tensor:
     """imageformation.py:59: (argwhere(lightsource) - pn//2).int(), row-major, as int32 [S,2]
     on the bitmap's device."""

@@ -26,7 +26,7 @@ if sys.argv[1] == "--child":
     sys.exit(0)
 pn, K = sys.argv[1], sys.argv[2]
 for lib in sys.argv[3].split(","):
-    env = dict(os.environ)
+    env = dict(os.environ, LITHO_ALLOW_DIAG="1")
     if lib != "default": env["LITHO_ABBE_LIB"] = os.path.join(ROOT, "build", "variants", f"lib_{lib}.so")
     print(f"== {lib}", flush=True)
     subprocess.run([sys.executable, __file__, "--child", pn, K], env=env)

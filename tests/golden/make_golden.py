@@ -361,9 +361,36 @@ def g9_config5_stack():
     save("g9_config5_stack.npz", **out)
 
 
+def g10_contiguous_shards():
+    """Long CONSECUTIVE runs of source points at the BASELINE sizes (what one rank of a many-GPU run accumulates):
+    config 2 (1024^2, annular, defocus pupil) points [40000, 42048) and config 3 (2048^2, quasar, demo pupil) points
+    [100000, 100512) of the row-major list, accumulated by the reference's own loop in its own order (fp32,
+    sequential).  A full-S image at these sizes would take the reference 2 h (config 2) to 24 h (config 3) on this
+    container's 8 cores, so full-S parity is pinned by these shard-sized runs plus the additivity property."""
+    print("G10 contiguous shards")
+    out = {}
+    for tag, pn, skind, ab, lo, n in (("cfg2", 1024, "annular", [0, 0, 0, 0, 100], 40000, 2048),
+                                      ("cfg3", 2048, "quasar", DEMO_AB, 100000, 512)):
+        mk = quiet(ref_mask.Mask, bernoulli_mask(pn), PS, CPU)
+        mft = mk.fraunhofer(WL, True)
+        eps, N = mk.calculateEpsilonN(mk.deltaK, PS, WL)
+        full = source(skind, pn, 0.4, 0.8)
+        pts = torch.argwhere(full)
+        bm = torch.zeros_like(full)
+        sel = pts[lo:lo + n]
+        bm[sel[:, 0], sel[:, 1]] = 1
+        pf = pupil_fn(pn, ab)
+        raw = raw_image(mft, pf, bm, N)
+        crop_stats(f"{tag}_raw", raw, out)
+        out[f"{tag}_range"] = np.array([lo, lo + n, pts.shape[0]], dtype=np.int64)
+        out[f"{tag}_first_last_shift"] = shifts_of(bm, pn)[[0, -1]]
+        print(f"   {tag}: points [{lo},{lo + n}) of {pts.shape[0]}  sum={float(raw.double().sum()):.6e}", flush=True)
+    save("g10_contiguous_shards.npz", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g10"]
     for g in which:
         {"g1": g1_sources, "g2": g2_pupils, "g3": g3_mask_spectra, "g4": g4_fields,
-         "g5": g5_images, "g6": g6_through_focus, "g8": g8_large_pupils, "g9": g9_config5_stack}[g]()
+         "g5": g5_images, "g6": g6_through_focus, "g8": g8_large_pupils, "g9": g9_config5_stack, "g10": g10_contiguous_shards}[g]()

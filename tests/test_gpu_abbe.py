@@ -296,6 +296,82 @@ def test_stack_plane_chunk_knob_and_generic_variant(L, dev, monkeypatch):
     assert rel_max(ref[3], chain) < TOL_IMAGE_MAX
 
 
+@pytest.mark.parametrize("tag,pn,skind,ab", [("cfg2", 1024, "annular", [0, 0, 0, 0, 100]), ("cfg3", 2048, "quasar", DEMO_AB)])
+def test_contiguous_shard_vs_golden(golden, L, dev, tag, pn, skind, ab):
+    """Shard-sized runs of CONSECUTIVE source points at the BASELINE sizes (config 2: 2048 points, config 3: 512
+    points), accumulated by the reference's own sequential fp32 loop (golden g10): many full batches through the
+    default kernels, compared on a centre crop, every row/column sum, the maximum and the total."""
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    g = golden("g10_contiguous_shards.npz")
+    lo, hi, S = (int(v) for v in g[f"{tag}_range"])
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    ls = L.LightSource(0.4, 0.8, pn, NA, device=dev)
+    sh = L.sourceShifts(ls.generateAnnular() if skind == "annular" else ls.generateQuasar(4, -math.pi / 8), pn)
+    assert sh.shape[0] == S
+    sel = sh[lo:hi]
+    assert np.array_equal(sel[[0, -1]].cpu().numpy(), g[f"{tag}_first_last_shift"])
+    pf = L.Pupil(pn, WL, NA, f16(ab), dev).generatePupilFunction()
+    raw = L.abbeIntensity(mft, pf, sel, N).cpu()
+    e = rel_max(crop_center(raw), g[f"{tag}_raw_crop"])
+    print(f"{tag} shard [{lo},{hi}): crop error rel-to-max {e:.2e}")
+    assert e < TOL_IMAGE_MAX
+    assert np.allclose(raw.double().sum(1).numpy(), g[f"{tag}_raw_rowsum"], rtol=2e-5)
+    assert np.allclose(raw.double().sum(0).numpy(), g[f"{tag}_raw_colsum"], rtol=2e-5)
+    assert abs(float(raw.max()) / float(g[f"{tag}_raw_max"]) - 1) < 2e-5
+    assert abs(float(raw.double().sum()) / float(g[f"{tag}_raw_sum"]) - 1) < 2e-6
+
+
+def test_full_source_additivity_config2(L, dev):
+    """BASELINE config 2 at its FULL source (S = 98,832): the image of all points == the sum of the images of 8
+    contiguous balanced shards (exactly what 8 ranks accumulate before the all-reduce), and == the single-wait
+    abbeImage path.  This is the multi-GPU invariant (SURVEY 8e measured 3.5e-7 for the reference itself)."""
+    from lithographysimulator_amd.distributed import shard_bounds
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    pn = 1024
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    bm = L.LightSource(0.4, 0.8, pn, NA, device=dev).generateAnnular()
+    pf = L.Pupil(pn, WL, NA, f16([0, 0, 0, 0, 100]), dev).generatePupilFunction()
+    sh = L.sourceShifts(bm, pn)
+    assert sh.shape[0] == 98832
+    whole = L.abbeIntensity(mft, pf, sh, N)
+    parts = torch.zeros_like(whole, dtype=torch.float64)
+    for r in range(8):
+        lo, hi = shard_bounds(sh.shape[0], r, 8)
+        parts += L.abbeIntensity(mft, pf, sh[lo:hi], N).double()
+    err = float((parts - whole.double()).abs().max() / whole.double().max())
+    print(f"config 2 full source: 8-shard sum vs single run, rel-to-max {err:.2e}")
+    assert err < 2e-6
+    img = L.abbeImage(mask, mft, pf, bm, PS, mask.deltaK, WL, True, dev)      # asynchronous count path
+    assert rel_max(img.cpu(), L.postProcess(whole, eps).cpu()) < 1e-6
+    norm = L.abbeImage(mask, mft, pf, bm, PS, mask.deltaK, WL, True, dev, normalize=True)
+    assert rel_max((norm * 98832).cpu(), img.cpu()) < 1e-6
+
+
+def test_async_count_path_edge_cases(L, dev):
+    """sourceShiftsAsync + abbeIntensity(count=...): empty source, one point, and agreement with the synchronous list."""
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    pn = 256
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    pf = L.Pupil(pn, WL, NA, f16(DEMO_AB), dev).generatePupilFunction()
+    empty = torch.zeros((pn, pn), dtype=torch.int64, device=dev)
+    sh, cnt = L.sourceShiftsAsync(empty, pn)
+    raw, S = L.abbeIntensity(mft, pf, sh, N, count=cnt)
+    assert S == 0 and float(raw.abs().max()) == 0.0
+    assert float(L.abbeImage(mask, mft, pf, empty, PS, mask.deltaK, WL, True, dev).abs().max()) == 0.0
+    bm = L.LightSource(0.4, 0.8, pn, NA, device=dev).generateQuasar(4, -math.pi / 8)
+    sh, cnt = L.sourceShiftsAsync(bm, pn)
+    raw, S = L.abbeIntensity(mft, pf, sh, N, count=cnt)
+    ref_list = L.sourceShifts(bm, pn)
+    assert S == ref_list.shape[0] and torch.equal(sh[:S], ref_list)
+    assert rel_max(raw.cpu(), L.abbeIntensity(mft, pf, ref_list, N).cpu()) < 1e-6
+
+
 # ------------------------------------------------------------------ size-independent properties at full size
 def test_properties_2048(L, dev):
     """At BASELINE config 3's full grid (2048^2, N = 4096): the Abbe sum is additive over any

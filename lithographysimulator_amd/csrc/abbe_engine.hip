@@ -214,7 +214,7 @@ static int env_int(const char* name, int dflt)
 
 // Tuning / test knobs.  Read ONCE per C-ABI call (the parity tests flip them between calls), never per launch.
 struct Knobs {
-    int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk;
+    int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk, xsplit;
     static Knobs read()
     {
         Knobs k;
@@ -223,11 +223,12 @@ struct Knobs {
         k.groups = env_int("LITHO_ABBE_GROUPS", 0);
         k.batch = env_int("LITHO_ABBE_BATCH", 0);
         k.xchunk = env_int("LITHO_ABBE_XCHUNK", 0);
-        k.tile = env_int("LITHO_ABBE_TILE", 4);
+        k.tile = env_int("LITHO_ABBE_TILE", 0);          // 0 = automatic (8 columns on the wave-kernel path, else 4)
         k.w64 = env_int("LITHO_ABBE_W64", 1);
-        k.w64_8192 = env_int("LITHO_ABBE_W64_8192", 0);
+        k.w64_8192 = env_int("LITHO_ABBE_W64_8192", 1);
         k.w64x = env_int("LITHO_ABBE_W64X", 0);
         k.plane_chunk = env_int("LITHO_ABBE_PLANE_CHUNK", 0);
+        k.xsplit = env_int("LITHO_ABBE_XSPLIT", 1);
         return k;
     }
 };
@@ -357,7 +358,7 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     int general = (!nowrap || kn.force_general) ? 1 : 0;
     if (general) { r0 = 0; c0 = 0; h = pn; wdt = pn; }
     PassGeom g;
-    make_geom(g, pn, N, r0, c0, h, wdt, general, kn.tile);
+    make_geom(g, pn, N, r0, c0, h, wdt, general, kn.tile > 0 ? kn.tile : 4);
     const SizeOps* ops = size_ops(ilog2(N));
     if (!ops) return LITHO_E_ARG;
     const int variant = pick_variant(g, kn);
@@ -366,13 +367,22 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     // count that makes it a whole number of full-occupancy rounds (256 CUs x workgroups per CU).
     const int l2n = ilog2(N);
     const int lines_per_wg = (N / 16 >= 64) ? 1 : 64 / (N / 16);
-    // wave-per-line y-pass (k_ypass_wave): N = 2 pn with pn = 512, 1024, 2048; pn = 4096 is opt-in (slower there)
-    const bool w64_ok = (pn * 2 == N) && (N == 1024 || N == 2048 || N == 4096 || (N == 8192 && kn.w64_8192));
+    // wave-per-line y-pass (k_ypass_wave): N = 2 pn with pn = 512, 1024, 2048; pn = 4096: pair-of-waves kernel (k_ypass_pair)
+    const bool w64_ok = (pn * 2 == N) && (N == 1024 || N == 2048 || N == 4096 || (N == 8192 && kn.w64_8192));   // w64_8192 defaults to 1
     const bool w64_shape = w64_ok && kn.w64;
-    const bool use_w64 = variant == 1 && w64_shape && g.tcl == 2;
-    const int wave_tiles = (N == 1024) ? 2 : 1;                       // T tiles per wave-kernel workgroup
-    const int tile_blocks = w64_shape ? (g.nt + wave_tiles - 1) / wave_tiles : (g.nt + lines_per_wg - 1) / lines_per_wg;
-    const int resident = 256 * (w64_shape ? (N <= 2048 ? 4 : (N == 4096 ? 2 : 1)) : l2n <= 12 ? 3 : (l2n == 13 ? 2 : 1));
+    // T tile width.  The x-pass's T stores are bound by the memory system's rate for partial-line writes: measured
+    // (scripts/ubench/write_bw.hip) 2.2 TB/s for 32-byte granules (4-column tiles), 3.4 TB/s for 64-byte granules
+    // (8 columns), 5.2 TB/s for whole 128-byte lines.  The wave kernels read 8-column tiles at no extra cost, the
+    // radix-16 y-pass does not (measured in round 1), so: 8 columns on the wave path, 4 elsewhere.
+    if (kn.tile <= 0 && variant == 1 && w64_shape && !kn.w64x) set_tile(g, h, 8);
+    const bool use_w64 = variant == 1 && w64_shape && (g.tcl == 2 || g.tcl == 3);
+    const int wave_cols = N == 1024 ? 8 : (N == 8192 ? 2 : 4);        // columns per wave-kernel workgroup
+    const int tc = 1 << g.tcl;
+    const int wave_wpt = tc > wave_cols ? tc / wave_cols : 1;         // workgroups that share one T tile
+    const int tile_blocks = !use_w64 ? (g.nt + lines_per_wg - 1) / lines_per_wg
+                            : wave_wpt == 1 ? (pn + wave_cols - 1) / wave_cols
+                                            : wave_wpt * (((pn + tc - 1) / tc + 7) / 8 * 8);
+    const int resident = 256 * (use_w64 ? (N <= 2048 ? 4 : 2) : l2n <= 12 ? 3 : (l2n == 13 ? 2 : 1));
     int a_ = tile_blocks, b_ = resident;
     while (b_) { const int t_ = a_ % b_; a_ = b_; b_ = t_; }
     int Gtot = resident / a_;                                  // groups that fill whole rounds
@@ -388,7 +398,9 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     if (PC > g_cap(pn)) PC = g_cap(pn);
     int G = Gtot / PC;                                         // groups per plane
     if (G < 1) G = 1;
-    const bool fused_x = !general && variant >= 0 && !(use_w64 && N == 4096 && kn.w64x);
+    // N = 8192 = 2 pn: each row as two 4096-point transforms (k_xpass_split) instead of the 8192-point engine
+    const bool split_x = !general && variant == 1 && N == 8192 && g.tcl >= 2 && kn.xsplit;
+    const bool fused_x = !split_x && !general && variant >= 0 && !(use_w64 && N == 4096 && kn.w64x && g.tcl == 2);
 
     // Batch = source points per launch pair.  The intermediate T of one batch (PC planes x points) should stay
     // resident in the 256 MiB Infinity Cache between the two passes (measured at 2048^2: 63 items = 1 GiB ->
@@ -431,7 +443,11 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
             const int nb = (int)((S - s0 < bs) ? (S - s0) : bs);
             const int* sh = shifts + 2 * s0;
             if (fresh) { marks.add(-1, 0); fresh = false; }
-            if (fused_x) {
+            if (split_x) {
+                for (int q = 0; q < pc; ++q)
+                    HIP_TRY(ops->xpass_split(Pc + (size_t)q * pn * pn, M, sh, w.T + (size_t)q * nb * g.t_point, w.twtab, g,
+                                             nb, xchunk, st));
+            } else if (fused_x) {
                 for (int q = 0; q < pc;) {
                     const int np = variant == 0 ? 1 : (pc - q >= 4) ? 4 : (pc - q >= 2 ? 2 : 1);
                     HIP_TRY(ops->xpass_abbe(variant, np, Pc + (size_t)q * pn * pn, M, sh,
@@ -480,7 +496,7 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     }
     g_last_plan[0] = general; g_last_plan[1] = r0; g_last_plan[2] = c0; g_last_plan[3] = h;
     g_last_plan[4] = wdt; g_last_plan[5] = bs; g_last_plan[6] = nx; g_last_plan[7] = variant;
-    g_last_plan[8] = PC; g_last_plan[9] = G; g_last_plan[10] = xchunk; g_last_plan[11] = fused_x ? 1 : 0;
+    g_last_plan[8] = PC; g_last_plan[9] = G; g_last_plan[10] = xchunk; g_last_plan[11] = fused_x ? 1 : (split_x ? 2 : 0);
     return LITHO_OK;
 }
 

@@ -80,6 +80,13 @@ __device__ __forceinline__ float2 buf_load_c64(__amdgpu_buffer_rsrc_t r, unsigne
     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
     return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
 }
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void buf_store_c64x2(__amdgpu_buffer_rsrc_t r, unsigned off, float2 a, float2 b) {
+    u32x4 w;
+    w.x = __float_as_uint(a.x); w.y = __float_as_uint(a.y);
+    w.z = __float_as_uint(b.x); w.w = __float_as_uint(b.y);
+    __builtin_amdgcn_raw_buffer_store_b128(w, r, off, 0, 0);
+}
 __device__ __forceinline__ void buf_store_c64(__amdgpu_buffer_rsrc_t r, unsigned off, float2 v) {
     u32x2 w;
     w.x = __float_as_uint(v.x);
@@ -229,6 +236,100 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
                 if constexpr ((OUT >> m) & 1u) buf_store_c64(rT, toff[m], x[m]);
 #endif
             });
+        });
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// x-pass for N = 2 pn at the sizes where the N-point engine is the weak one (N = 8192: 512-thread workgroups,
+// 128-register cap).  Decimation in frequency turns every row into TWO N/2-point transforms:
+//     out[2v + p] = sum_k (in[k] w_N^(k p)) w_{N/2}^(k v),      p = 0, 1,   v in [-pn/4, pn/4),
+// (the pn/2 + 1 live inputs do not alias in N/2 points), both run by the better-tuned N/2-point engine with the
+// slot sets IN = natural_in_mask(0), OUT = out_mask(1).  The factor w_N^(k p) is folded into a second register copy
+// of the pupil row, the mask-spectrum window is gathered once for both, and because the SAME thread ends up with
+// the adjacent columns 2v and 2v + 1, T is written with 16-byte stores in its usual layout: the y-pass does not
+// know the difference.
+// ----------------------------------------------------------------------------------
+template <int LOG2N>
+__global__ __launch_bounds__(Launch<LOG2N - 1>::THREADS, Launch<LOG2N - 1>::WAVES) void k_xpass_split(
+    const float2* __restrict__ P, const float2* __restrict__ M, const int* __restrict__ shifts,
+    float2* __restrict__ Tbuf, const float2* __restrict__ twtab, PassGeom g, int nb, int chunk)
+{
+    using F = LineFFT<LOG2N - 1, +1>;
+    using LC = Launch<LOG2N - 1>;
+    static_assert(LC::L == 1, "split x-pass: one row per workgroup");
+    constexpr unsigned IN = natural_in_mask(0), OUT = out_mask(1);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* smem = reinterpret_cast<float2*>(smem_raw);
+    const int lt = threadIdx.x;
+    float2* lds = smem;
+
+    typename F::Twiddles tw;
+    F::load_twiddles(tw, twtab, lt, smem + LC::LDS_EXCH, threadIdx.x, LC::THREADS, 2);   // twtab = the N-point table
+
+    const int b = blockIdx.x, xcd = b & 7, i = b >> 3;           // XCD-aware row mapping, see k_xpass_abbe
+    const int a = (i >> 2) * 32 + xcd * 4 + (i & 3);
+    const bool active = a < g.rows;
+    const int r = g.ky0 + g.c + a;
+    const size_t plane_bytes = (size_t)g.pn * g.pn * sizeof(float2);
+    const __amdgpu_buffer_rsrc_t rM = make_rsrc(M, plane_bytes);
+    const __amdgpu_buffer_rsrc_t rP = make_rsrc(P, plane_bytes);
+
+    unsigned koff[16];
+    float2 pv0[16], pv1[16];
+    static_for<0, 16>([&](auto e_) {
+        constexpr int e = decltype(e_)::value;
+        if constexpr ((IN >> e) & 1u) {
+            int k;
+            const bool ok = centred_index(lt + F::T * e, F::N, g.kx0, g.kx1, k) && active;
+            koff[e] = ok ? (unsigned)(g.c + k) : BUF_OOB;
+            pv0[e] = buf_load_c64(rP, ok ? ((unsigned)r * g.pn + koff[e]) * 8u : BUF_OOB);
+            pv1[e] = cmul(pv0[e], twtab[(k + 2 * F::N) & (2 * F::N - 1)]);       // w_N^k, k may be negative
+        }
+    });
+    unsigned toff[16];           // byte offset of the column PAIR (2v, 2v + 1) inside one T item
+    static_for<0, 16>([&](auto m_) {
+        constexpr int m = decltype(m_)::value;
+        if constexpr ((OUT >> m) & 1u) {
+            int v;
+            const bool ok = centred_index(lt + F::T * m, F::N, -(g.c >> 1), g.c >> 1, v) && active;
+            toff[m] = ok ? t_offset(g, a, (unsigned)(2 * v + g.c)) * 8u : BUF_OOB;
+        }
+    });
+
+    const int s_begin = blockIdx.y * chunk;
+    const int s_end = min(nb, s_begin + chunk);
+    int flip = 0;
+    for (int s = s_begin; s < s_end; ++s) {
+        const int dy = shifts[2 * s], dx = shifts[2 * s + 1];
+        const unsigned mrow = (unsigned)(r + dy) * g.pn + dx;
+        float2 mv[16];
+        static_for<0, 16>([&](auto e_) {
+            constexpr int e = decltype(e_)::value;
+            if constexpr ((IN >> e) & 1u) mv[e] = buf_load_c64(rM, koff[e] != BUF_OOB ? (mrow + koff[e]) * 8u : BUF_OOB);
+        });
+        float2 x[16], even[16];
+        static_for<0, 16>([&](auto e_) {
+            constexpr int e = decltype(e_)::value;
+            if constexpr ((IN >> e) & 1u) x[e] = cmul(pv0[e], mv[e]);
+            else x[e] = make_float2(0.f, 0.f);
+        });
+        F::template run<LC::NBUF>(x, tw, lds, lt, flip);
+        static_for<0, 16>([&](auto m_) {
+            constexpr int m = decltype(m_)::value;
+            if constexpr ((OUT >> m) & 1u) even[m] = x[m];
+        });
+        static_for<0, 16>([&](auto e_) {
+            constexpr int e = decltype(e_)::value;
+            if constexpr ((IN >> e) & 1u) x[e] = cmul(pv1[e], mv[e]);
+            else x[e] = make_float2(0.f, 0.f);
+        });
+        F::template run<LC::NBUF>(x, tw, lds, lt, flip);
+        const __amdgpu_buffer_rsrc_t rT =
+            make_rsrc(Tbuf + (size_t)s * g.t_point, (size_t)g.t_point * sizeof(float2));
+        static_for<0, 16>([&](auto m_) {
+            constexpr int m = decltype(m_)::value;
+            if constexpr ((OUT >> m) & 1u) buf_store_c64x2(rT, toff[m], even[m], x[m]);
         });
     }
 }
@@ -507,12 +608,14 @@ __global__ __launch_bounds__(256, 2) void k_xpass_w64(
 // ----------------------------------------------------------------------------------
 template <int LOG2N>
 struct WaveShape {
-    static_assert(LOG2N >= 10 && LOG2N <= 13, "wave-per-line y-pass: N = 1024 .. 8192");
+    static_assert(LOG2N >= 10 && LOG2N <= 12, "wave-per-line y-pass: N = 1024 .. 4096 (N = 8192: k_ypass_pair)");
     static constexpr int LS = LOG2N / 2;                     // 5, 5, 6, 6
     static constexpr int D = 1 << (LOG2N - 2 * LS);          // 1, 2, 1, 2
     using W = WaveSq<LS>;
     static constexpr int S = W::S;
-    static constexpr int THREADS = (LS == 6 && D == 2) ? 512 : 256;
+    // (one 512-thread workgroup per 8-column tile, so that every consumer of a 64-byte row granule sits on one CU,
+    // was measured slower at 2048^2: y-pass 10.0 vs 9.5 us/point)
+    static constexpr int THREADS = 256;
     static constexpr int UNITS = THREADS / S;                // sub-transforms per workgroup
     static constexpr int COLS = UNITS / D;                   // columns per workgroup (4 or 8)
     static constexpr int TILES = COLS / 4;                   // T tiles per workgroup
@@ -524,11 +627,30 @@ struct WaveShape {
     static constexpr int MINWAVES = LS == 5 ? LITHO_WAVE32_MINWAVES : 2;   // S = 32 needs few registers: 4 workgroups per CU
 };
 
-template <int LOG2N>
+// Block index -> first column of the workgroup.  A workgroup covers COLS columns of T tiles that are TC columns wide;
+// when a tile is shared by WPT = TC / COLS workgroups these are blocks b, b + 8, ... (same XCD, back to back), so the
+// tile's granules are served by one L2.  The grid must have wave_grid_x<TC, COLS>(pn) blocks.
+template <int TC, int COLS>
+__device__ __forceinline__ int wave_first_column(int b)
+{
+    constexpr int WPT = TC > COLS ? TC / COLS : 1;
+    if constexpr (WPT == 1) return b * COLS;
+    else return (((b / (8 * WPT)) * 8 + (b & 7)) * TC) + ((b >> 3) % WPT) * COLS;
+}
+template <int TC, int COLS>
+static inline int wave_grid_x(int pn)
+{
+    constexpr int WPT = TC > COLS ? TC / COLS : 1;
+    if constexpr (WPT == 1) return (pn + COLS - 1) / COLS;
+    else return WPT * (((pn + TC - 1) / TC + 7) / 8 * 8);
+}
+
+template <int LOG2N, int TC>
 __global__ __launch_bounds__(WaveShape<LOG2N>::THREADS, WaveShape<LOG2N>::MINWAVES) void k_ypass_wave(
     const float2* __restrict__ Tbuf, float* __restrict__ slab, const float2* __restrict__ twtab,
     PassGeom g, int nb, int G, int gstride)
 {
+    static_assert(TC == 4 || TC == 8, "T tiles are 4 or 8 columns wide");
     using WS = WaveShape<LOG2N>;
     using W = typename WS::W;
     constexpr int S = WS::S, D = WS::D, JLIVE = WS::JLIVE, N = 1 << LOG2N;
@@ -546,25 +668,27 @@ __global__ __launch_bounds__(WaveShape<LOG2N>::THREADS, WaveShape<LOG2N>::MINWAV
 
     // The tile index is wave-uniform (a wave's units cover at most one tile); readfirstlane makes that
     // provable, otherwise every buffer access through the tile's descriptor becomes a waterfall loop.
-    const int tile = blockIdx.x * WS::TILES + (WS::TILES > 1 ? __builtin_amdgcn_readfirstlane(colg >> 2) : 0);
-    const int col = colg & 3;
+    const int qx = wave_first_column<TC, WS::COLS>(blockIdx.x) + colg;
+    const int tile = __builtin_amdgcn_readfirstlane(qx / TC);
+    const int col = qx & (TC - 1);
     const int plane = blockIdx.y / G, grp = blockIdx.y - plane * G;      // see k_ypass_acc
     Tbuf += (size_t)plane * nb * g.t_point;
     slab += (size_t)plane * gstride * g.nt * 4 * g.pn;
-    const bool active = tile < g.nt;
+    const bool active = tile * TC < g.pn;
     float acc[S / 2];
     static_for<0, S / 2>([&](auto i) { acc[i] = 0.f; });
 
     // Live input slots j (sub-transform sample n' = l + S j): k = n' for j <= JLIVE, k = n' - S*S for the upper
     // ones (sample n' + N - S*S of the full line); T row a = k - ky0.  The descriptor is windowed on this tile's
-    // rows ([tile][row][4] layout, 32 B per row): the range check is the validity test.
-    const unsigned tile_bytes = active ? (unsigned)g.rows * 32u : 0u;
-    const unsigned vb = (unsigned)(l - g.ky0) * 32u + (unsigned)col * 8u;
-    auto slot_off = [&](int j) { return vb + (unsigned)(j <= JLIVE ? 32 * S * j : 32 * S * j - 32 * S * S); };
+    // rows ([tile][row][TC] layout, RB = 8 TC bytes per row): the range check is the validity test.
+    constexpr int RB = 8 * TC;
+    const unsigned tile_bytes = active ? (unsigned)g.rows * RB : 0u;
+    const unsigned vb = (unsigned)(l - g.ky0) * RB + (unsigned)col * 8u;
+    auto slot_off = [&](int j) { return vb + (unsigned)(j <= JLIVE ? RB * S * j : RB * S * j - RB * S * S); };
 
     for (int s = grp; s < nb; s += G) {
         const __amdgpu_buffer_rsrc_t rT =
-            make_rsrc(Tbuf + (size_t)s * g.t_point + (size_t)(active ? tile : 0) * g.rows * 4, tile_bytes);
+            make_rsrc(Tbuf + (size_t)s * g.t_point + (size_t)(active ? tile : 0) * g.rows * TC, tile_bytes);
         float2 x[S];
         static_for<0, S>([&](auto j_) {
             constexpr int j = decltype(j_)::value;
@@ -595,9 +719,7 @@ __global__ __launch_bounds__(WaveShape<LOG2N>::THREADS, WaveShape<LOG2N>::MINWAV
         });
     }
 
-    if (!active) return;
-    const int qx = tile * 4 + col;
-    if (qx >= g.pn) return;
+    if (!active || qx >= g.pn) return;
     float* srow = slab + ((size_t)grp * g.nt * 4 + qx) * g.pn;
     static_for<0, S / 2>([&](auto i_) {
         constexpr int i = decltype(i_)::value;
@@ -605,6 +727,75 @@ __global__ __launch_bounds__(WaveShape<LOG2N>::THREADS, WaveShape<LOG2N>::MINWAV
         const int n = l + S * k2;
         const int v = n < S * S / 2 ? n : n - S * S;        // bin of the sub-transform
         srow[D * v + p + g.c] += acc[i];                    // bin u = D v + p of the full line
+    });
+}
+
+// ----------------------------------------------------------------------------------
+// y-pass for N = 8192, pn = 4096 (BASELINE config 4), pupil inside the unit disk: a PAIR of waves per column
+// (WaveSq<6>::run_pair).  Each wave loads 17 live slots (like the 4096-point kernel), runs a pruned-input pass A,
+// exchanges with its partner at the transpose, and accumulates the 32 kept bins of its half of the line.
+// Workgroup = 4 waves = 2 columns; the two workgroups that share a 4-column T tile are blocks b and b + 8 (same
+// XCD, back to back) so the tile's 32-byte granules are served by one L2.
+// ----------------------------------------------------------------------------------
+template <int LOG2N, int TC>
+__global__ __launch_bounds__(256, 2) void k_ypass_pair(
+    const float2* __restrict__ Tbuf, float* __restrict__ slab, const float2* __restrict__ twtab,
+    PassGeom g, int nb, int G, int gstride)
+{
+    static_assert(LOG2N == 13, "pair-of-waves y-pass: N = 8192");
+    using W = WaveSq<6>;
+    constexpr int S = 64, N = 1 << LOG2N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int par = wv & 1, pair = wv >> 1;
+    float* mat_own = smem + wv * W::LDS_FLOATS;
+    const float* mat_other = smem + (wv ^ 1) * W::LDS_FLOATS;
+    typename W::LaneTwiddles tw;
+    W::load_lane_twiddles(tw, twtab, lane + S * par, 1);
+
+    static_assert(TC == 4 || TC == 8, "T tiles are 4 or 8 columns wide");
+    const int qx = wave_first_column<TC, 2>(blockIdx.x) + pair;
+    const int tile = qx / TC, col = qx & (TC - 1);
+    const int plane = blockIdx.y / G, grp = blockIdx.y - plane * G;      // see k_ypass_acc
+    Tbuf += (size_t)plane * nb * g.t_point;
+    slab += (size_t)plane * gstride * g.nt * 4 * g.pn;
+    const bool active = tile * TC < g.pn;
+    float acc[S / 2];
+    static_for<0, S / 2>([&](auto i) { acc[i] = 0.f; });
+
+    // slot j <-> sample n = lane + 64 par + 128 j: k = n for j <= 8, k = n - N for j >= 56; T row a = k - ky0.
+    constexpr int RB = 8 * TC;                                            // bytes per T row inside a tile
+    const unsigned tile_bytes = active ? (unsigned)g.rows * RB : 0u;
+    const unsigned vb = (unsigned)(lane + S * par - g.ky0) * RB + (unsigned)col * 8u;
+    auto slot_off = [&](int j) { return vb + (unsigned)(j <= 8 ? RB * 2 * S * j : RB * 2 * S * j - RB * N); };
+
+    for (int s = grp; s < nb; s += G) {
+        const __amdgpu_buffer_rsrc_t rT =
+            make_rsrc(Tbuf + (size_t)s * g.t_point + (size_t)(active ? tile : 0) * g.rows * TC, tile_bytes);
+        float2 x[S];
+        static_for<0, S>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            if constexpr (j <= 8 || j >= S - 8) x[j] = buf_load_c64(rT, slot_off(j));
+            else x[j] = make_float2(0.f, 0.f);
+        });
+        W::run_pair(x, tw, mat_own, mat_other, lane, par);
+        static_for<0, S / 2>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            constexpr int k2 = i < S / 4 ? i : S / 2 + i;
+            const float2 v = x[W::brev(k2)];
+            acc[i] = fmaf(v.x, v.x, fmaf(v.y, v.y, acc[i]));
+        });
+    }
+
+    if (!active || qx >= g.pn) return;
+    float* srow = slab + ((size_t)grp * g.nt * 4 + qx) * g.pn;
+    static_for<0, S / 2>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        constexpr int k2 = i < S / 4 ? i : S / 2 + i;
+        constexpr int ubase = k2 < S / 2 ? 2 * S * k2 : 2 * S * k2 - N;      // bin u = lane + 64 par + 128 k2 (mod N, centred)
+        srow[ubase + lane + S * par + g.c] += acc[i];
     });
 }
 
@@ -654,6 +845,9 @@ struct SizeOps {
                              const float2* tw, const PassGeom& g, int nb, int chunk, hipStream_t st);
     hipError_t (*xpass_general)(const AbbeLoader& ld, float2* T, const float2* tw, const PassGeom& g, int nb,
                                 hipStream_t st);
+    // N = 2 pn as two N/2-point transforms per row (k_xpass_split; N = 8192 only): hipErrorNotSupported otherwise
+    hipError_t (*xpass_split)(const float2* P, const float2* M, const int* shifts, float2* T, const float2* tw,
+                              const PassGeom& g, int nb, int chunk, hipStream_t st);
     hipError_t (*xpass_real_fwd)(const RealImageLoader& ld, float2* T, const float2* tw, const PassGeom& g,
                                  hipStream_t st);
     // y-pass over `planes` planes x G groups per plane (grid.y = planes * G); slab of (plane, group) =
@@ -739,6 +933,22 @@ struct SizeImpl {
                            tw, g);
         return hipGetLastError();
     }
+    static hipError_t xpass_split(const float2* P, const float2* M, const int* shifts, float2* T, const float2* tw,
+                                  const PassGeom& g, int nb, int chunk, hipStream_t st)
+    {
+        if constexpr (LOG2N == 13) {
+            using LH = Launch<LOG2N - 1>;
+            static LdsOnce once;
+            auto kern = k_xpass_split<LOG2N>;
+            hipError_t e = set_lds(once, kern, LH::LDS_BYTES);
+            if (e != hipSuccess) return e;
+            dim3 grid((g.rows + 31) / 32 * 32, (nb + chunk - 1) / chunk);
+            hipLaunchKernelGGL(kern, grid, dim3(LH::THREADS), LH::LDS_BYTES, st, P, M, shifts, T, tw, g, nb, chunk);
+            return hipGetLastError();
+        } else {
+            return hipErrorNotSupported;
+        }
+    }
     static hipError_t xpass_real_fwd(const RealImageLoader& ld, float2* T, const float2* tw, const PassGeom& g,
                                      hipStream_t st)
     {
@@ -790,21 +1000,39 @@ struct SizeImpl {
             return hipErrorNotSupported;
         }
     }
-    static hipError_t ypass_w64(const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb, int planes,
-                                int G, int gstride, hipStream_t st)
+    template <int TC>
+    static hipError_t yw(const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb, int planes, int G,
+                         int gstride, hipStream_t st)
     {
-        if constexpr (LOG2N >= 10 && LOG2N <= 13) {
+        if constexpr (LOG2N == 13) {
+            static LdsOnce once;
+            constexpr size_t lds = 4 * WaveSq<6>::LDS_FLOATS * sizeof(float);
+            auto kern = k_ypass_pair<LOG2N, TC>;
+            hipError_t e = set_lds(once, kern, lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, 2>(g.pn), planes * G), dim3(256), lds, st, T, slab, tw, g, nb, G,
+                               gstride);
+            return hipGetLastError();
+        } else if constexpr (LOG2N >= 10 && LOG2N <= 12) {
             static LdsOnce once;
             using WS = WaveShape<LOG2N>;
-            auto kern = k_ypass_wave<LOG2N>;
+            auto kern = k_ypass_wave<LOG2N, TC>;
             hipError_t e = set_lds(once, kern, WS::LDS_BYTES);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, dim3((g.nt + WS::TILES - 1) / WS::TILES, planes * G), dim3(WS::THREADS),
-                               WS::LDS_BYTES, st, T, slab, tw, g, nb, G, gstride);
+            hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, WS::COLS>(g.pn), planes * G), dim3(WS::THREADS), WS::LDS_BYTES,
+                               st, T, slab, tw, g, nb, G, gstride);
             return hipGetLastError();
         } else {
             return hipErrorNotSupported;
         }
+    }
+    // wave-per-line / pair-of-waves y-pass; the T tile width (4 or 8 columns) comes from g.tcl
+    static hipError_t ypass_w64(const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb, int planes,
+                                int G, int gstride, hipStream_t st)
+    {
+        if (g.tcl == 2) return yw<4>(T, slab, tw, g, nb, planes, G, gstride, st);
+        if (g.tcl == 3) return yw<8>(T, slab, tw, g, nb, planes, G, gstride, st);
+        return hipErrorNotSupported;
     }
     static hipError_t ypass_field(int sign, const float2* T, float2* field, const float2* tw, const PassGeom& g,
                                   hipStream_t st)
@@ -832,7 +1060,7 @@ struct SizeImpl {
     const SizeOps* size_ops_##L2()                                                                   \
     {                                                                                                \
         static const SizeOps ops{&SizeImpl<L2>::xpass_abbe, &SizeImpl<L2>::xpass_general,            \
-                                 &SizeImpl<L2>::xpass_real_fwd, &SizeImpl<L2>::ypass_acc,            \
+                                 &SizeImpl<L2>::xpass_split, &SizeImpl<L2>::xpass_real_fwd, &SizeImpl<L2>::ypass_acc,            \
                                  &SizeImpl<L2>::ypass_field, &SizeImpl<L2>::xpass_w64,               \
                                  &SizeImpl<L2>::ypass_w64};                                          \
         return &ops;                                                                                 \

@@ -166,21 +166,23 @@ struct LineFFT {
     // table[n] = exp(+2 pi i n / N); SIGN < 0 conjugates on the fly.  Fills the LDS tables
     // cooperatively (call with every thread of the workgroup, then lds_barrier) and the
     // register-resident set of thread t.
+    // tstride: the table may belong to a transform `tstride` times longer (entry tstride * n = exp(2 pi i n / N)).
     __device__ static __forceinline__ void load_twiddles(Twiddles& tw, const float2* __restrict__ table, int t,
-                                                         float2* lds_tables, int wg_tid, int wg_threads) {
+                                                         float2* lds_tables, int wg_tid, int wg_threads,
+                                                         int tstride = 1) {
         static_for<0, P16>([&](auto p_) {
             constexpr int p = decltype(p_)::value;
             constexpr int ns = ns_of(p);
             if constexpr (tw_in_lds(p)) {
                 for (int i = wg_tid; i < ns * 15; i += wg_threads) {
                     const int k = i / 15, r = i - k * 15 + 1;
-                    float2 w = table[k * r * (N / (16 * ns))];
+                    float2 w = table[tstride * k * r * (N / (16 * ns))];
                     if (SIGN < 0) w.y = -w.y;
                     lds_tables[lds_tw_offset(p) + i] = w;
                 }
             } else if constexpr (tw_in_reg(p)) {
                 const int k = t & (ns - 1);
-                const int step = k * (N / (16 * ns));
+                const int step = tstride * k * (N / (16 * ns));
                 static_for<1, 16>([&](auto r) {
                     float2 w = table[step * decltype(r)::value];
                     if (SIGN < 0) w.y = -w.y;

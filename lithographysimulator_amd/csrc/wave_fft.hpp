@@ -52,6 +52,19 @@ __device__ __forceinline__ float2 mul_root64(float2 v)
     }
 }
 
+// v * exp(+2 pi i M / 128), 0 <= M < 64 (compile-time constants; trivial cases folded)
+template <int M>
+__device__ __forceinline__ float2 mul_root128(float2 v)
+{
+    if constexpr (M % 2 == 0) {
+        return mul_root64<M / 2>(v);
+    } else {
+        constexpr double ang = 6.283185307179586476925 * M / 128.0;
+        const float wr = (float)__builtin_cos(ang), wi = (float)__builtin_sin(ang);      // folded at compile time
+        return make_float2(fmaf(v.x, wr, -v.y * wi), fmaf(v.x, wi, v.y * wr));
+    }
+}
+
 template <int LS>
 struct WaveSq {
     static_assert(LS == 5 || LS == 6, "S = 32 or 64");
@@ -131,6 +144,54 @@ struct WaveSq {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         dft_dif(x);                                    // slot brev(k2) = X[l + S k2]
+    }
+
+    // ------------------------------------------------------------------------------------------------
+    // 2*S*S-point lines (N = 8192 for S = 64) by a PAIR of waves.  With n = l + S J (J < 2S), u = M + 2S k2:
+    //   X[M + 2S k2] = sum_l wS^(l k2) [ w_N^(l M) sum_J x[l + S J] w_2S^(J M) ].
+    // Wave `par` (0/1) holds the samples with J = 2 j + par in slot j (n = l + S par + 2S j), runs the S-point
+    // pass A on them, A_par[l,m] (m < S), and applies ITS lane twiddle w_N^((l + S par) m): B_0 = w_N^(l m) A_0,
+    // B_1 = w_N^(l m) w_2S^m A_1.  Then
+    //   Z[l, m]     = B_0 + B_1                    (M = m,     handled by wave 0)
+    //   Z[l, m + S] = w_2S^l (B_0 - B_1)           (M = m + S, handled by wave 1)
+    // so the two waves exchange B through LDS AT the transpose that pass B needs anyway: each wave writes its own
+    // S x S matrix and reads column `lane` of BOTH.  The factor w_2S^l is a compile-time constant per slot after
+    // the transpose.  On return slot brev(k2) = X[lane + S par + 2S k2].  Four workgroup barriers per line (the
+    // partner's data must be complete before the reads, and consumed before the next overwrite); every wave of the
+    // workgroup must call this the same number of times.  `tw` = load_lane_twiddles(table_N, l + S par, 1).
+    // ------------------------------------------------------------------------------------------------
+    __device__ static __forceinline__ void run_pair(float2 (&x)[S], const LaneTwiddles& tw, float* mat_own,
+                                                    const float* mat_other, int lane, int par)
+    {
+        static_assert(LS == 6, "pair transform: S = 64");
+        dft_dif(x);                                    // slot brev(m) = A_par[l, m]
+        static_for<0, S>([&](auto m_) {
+            constexpr int m = decltype(m_)::value;
+            constexpr int a = m >> 3, b = m & 7, sl = brev(m);
+            if constexpr (b != 0) x[sl] = cmul(x[sl], tw.row[b]);
+            if constexpr (a != 0) x[sl] = cmul(x[sl], tw.row[8 + a]);
+        });
+        float* const wr = mat_own + lane * (S + 1);
+        const float* const rd0 = (par ? mat_other : mat_own) + lane;      // B_0: wave 0's matrix
+        const float* const rd1 = (par ? mat_own : mat_other) + lane;      // B_1: wave 1's matrix
+        const float sgn = par ? -1.f : 1.f;
+        static_for<0, S>([&](auto m_) { constexpr int m = decltype(m_)::value; wr[m] = x[brev(m)].x; });
+        lds_barrier();
+        float re[S];
+        static_for<0, S>([&](auto r_) {
+            constexpr int r = decltype(r_)::value;
+            re[r] = fmaf(sgn, rd1[r * (S + 1)], rd0[r * (S + 1)]);
+        });
+        lds_barrier();
+        static_for<0, S>([&](auto m_) { constexpr int m = decltype(m_)::value; wr[m] = x[brev(m)].y; });
+        lds_barrier();
+        static_for<0, S>([&](auto r_) {
+            constexpr int r = decltype(r_)::value;
+            x[r] = make_float2(re[r], fmaf(sgn, rd1[r * (S + 1)], rd0[r * (S + 1)]));
+        });
+        lds_barrier();
+        if (par) static_for<1, S>([&](auto r_) { constexpr int r = decltype(r_)::value; x[r] = mul_root128<r>(x[r]); });
+        dft_dif(x);                                    // slot brev(k2) = X[lane + S par + 2S k2]
     }
 };
 

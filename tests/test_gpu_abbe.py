@@ -452,7 +452,11 @@ def test_wave_per_line_and_radix16_ypass_agree_2048(L, dev, monkeypatch):
     assert rel_max(wx, part) < 2e-6                     # the (slower, opt-in) wave-per-line x-pass
 
 
-def test_optin_wave_kernel_4096_agrees(L, dev, monkeypatch):
+def test_8192_kernels_agree_4096(L, dev, monkeypatch):
+    """BASELINE config 4's size (4096^2, N = 8192).  Default = k_xpass_split (each row as two 4096-point transforms,
+    16-byte T stores) + k_ypass_pair (a pair of waves per column).  The 8192-point radix-16 engine kernels they
+    replace must give the same image, in every combination, also for a through-focus stack."""
+    from lithographysimulator_amd import _native as nat
     from lithographysimulator_amd.synthetic import bernoulli_mask
     pn = 4096
     mask = L.Mask(bernoulli_mask(pn), PS, dev)
@@ -460,10 +464,24 @@ def test_optin_wave_kernel_4096_agrees(L, dev, monkeypatch):
     eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
     pf = L.Pupil(pn, WL, NA, f16(DEMO_AB), dev).generatePupilFunction()
     sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateQuasar(4, -math.pi / 8), pn)
-    sel = sh[(torch.arange(3, device=dev) * sh.shape[0]) // 3]
-    ref = L.abbeIntensity(mft, pf, sel, N).cpu()
-    w64 = _with_env(monkeypatch, L, {"LITHO_ABBE_W64_8192": "1"}, lambda: L.abbeIntensity(mft, pf, sel, N).cpu())
-    assert rel_max(w64, ref) < 2e-6
+    sel = sh[(torch.arange(11, device=dev) * sh.shape[0]) // 11]
+    nat.set_profiling(True)
+    try:
+        new = L.abbeIntensity(mft, pf, sel, N).cpu()
+        assert nat.last_plan()["fused_xpass"] == 2 and nat.last_profile()["ypass_kernel"] == "k_ypass_wave"
+        old = _with_env(monkeypatch, L, {"LITHO_ABBE_W64_8192": "0", "LITHO_ABBE_XSPLIT": "0"},
+                        lambda: L.abbeIntensity(mft, pf, sel, N).cpu())
+        assert nat.last_plan()["fused_xpass"] == 1 and nat.last_profile()["ypass_kernel"] == "k_ypass_acc"
+    finally:
+        nat.set_profiling(False)
+    assert rel_max(new, old) < 2e-6
+    for env in ({"LITHO_ABBE_W64_8192": "0"}, {"LITHO_ABBE_XSPLIT": "0"}):
+        mixed = _with_env(monkeypatch, L, env, lambda: L.abbeIntensity(mft, pf, sel[:3], N).cpu())
+        assert rel_max(mixed, L.abbeIntensity(mft, pf, sel[:3], N).cpu()) < 2e-6
+    stack = L.throughFocusPupils(pn, WL, NA, f16(DEMO_AB), [-90.0, 30.0, 110.0], dev)
+    both = L.abbeIntensity(mft, stack, sel[:4], N).cpu()
+    for k in range(3):
+        assert rel_max(both[k], L.abbeIntensity(mft, stack[k], sel[:4], N).cpu()) < 1e-6
 
 
 def test_stack_through_wave_kernel_2048(L, dev):

@@ -10,10 +10,10 @@ from helpers import (NA, PS, PUPIL_CASES, SOURCE_CASES, TOL_PHI, WL, f16, rel_ma
 
 pytestmark = pytest.mark.gpu
 
-# fp16 wavefront: the HIP kernel evaluates atan2/cos/sin/pow correctly rounded in fp32, torch-CPU
-# uses SLEEF (<= 1 ulp); after rounding to fp16 at most this fraction of pixels may differ, each by
-# one fp16 ulp of W.
-W_MISMATCH_FRACTION = 1e-4
+# fp16 wavefront: the HIP kernel evaluates atan2/cos/sin/pow correctly rounded in fp32, torch-CPU uses SLEEF
+# (<= 1 ulp), so a flipped fp16 rounding was budgeted for (<= 1e-5 of pixels).  OBSERVED on MI355X
+# (scripts/parity_probe.py, profiles/r02_parity_probe.txt): 0 mismatching pixels in all 14 pupil cases, 0 flipped
+# source pixels in all 10 large bitmaps -- so the tests assert exact equality.
 
 
 @pytest.fixture(scope="module")
@@ -50,12 +50,10 @@ def test_source_bitmaps_large(golden, L, dev, pn, name):
     g = golden("g1_sources.npz")
     bm = _source(L, dev, pn, **SOURCE_CASES[name]).cpu().numpy()
     ref = unpack_bitmap(g[f"packed_{name}_{pn}"], pn)
-    # annular sources involve only exactly-rounded ops: bit exact.  Quasar wedges compare an fp16
-    # angle from atan2: allow a handful of flips (none observed) and report them.
-    limit = 0 if SOURCE_CASES[name]["kind"] == "annular" else 4
-    assert int((bm != ref).sum()) <= limit
-    if limit == 0:
-        assert np.array_equal(sha256_packed(bm), g[f"sha256_{name}_{pn}"])
+    # bit exact, quasar wedges (fp16 angle from atan2) included: 0 flips observed, 0 allowed
+    flips = int((bm != ref).sum())
+    assert flips == 0, f"{flips} source pixels differ from the reference"
+    assert np.array_equal(sha256_packed(bm), g[f"sha256_{name}_{pn}"])
 
 
 def test_source_4096_counts(golden, L, dev):
@@ -85,16 +83,13 @@ def test_pupils(golden, L, dev, pn, name):
     p = L.Pupil(pn, WL, NA, None if ab is None else f16(ab), dev)
     W = p.generateWavefrontError().real.to(torch.float16).cpu()
     Wref = torch.from_numpy(g[f"W_{name}_{pn}"]).view(torch.float16)
-    bad = W != Wref
-    assert int(bad.sum()) <= max(1, int(W_MISMATCH_FRACTION * pn * pn))
-    if bad.any():     # a differing pixel is off by one fp16 ulp at most
-        assert float((W.float() - Wref.float())[bad].abs().max()) <= float(torch.finfo(torch.float16).eps) * float(Wref.float().abs().max()) * 2
+    mism = int((W != Wref).sum())
+    assert mism == 0, f"{mism} of {pn * pn} fp16 wavefront values differ from the reference"
     p2 = L.Pupil(pn, WL, NA, None if ab is None else f16(ab), dev)
     phi = p2.generatePupilFunction().cpu()
     ref = torch.from_numpy(g[f"phi_{name}_{pn}"])
     assert torch.equal(phi != 0, ref != 0)
-    good = ~bad
-    assert float((phi - ref).abs()[good].max()) < TOL_PHI
+    assert float((phi - ref).abs().max()) < TOL_PHI               # EVERY pixel (observed: <= 6e-8)
 
 
 def test_pupil_mutates_callers_coefficients_like_reference(L, dev):
@@ -117,8 +112,7 @@ def test_pupil_large(golden, L, dev, pn):
         assert int((phi != 0).sum()) == int(g[f"nz_{name}_{pn}"])
         sub = phi[::16, ::16]
         ref = torch.from_numpy(g[f"phisub_{name}_{pn}"])
-        close = (sub - ref).abs() < TOL_PHI
-        assert int((~close).sum()) <= 2
+        assert float((sub - ref).abs().max()) < TOL_PHI           # every sample (0 outliers observed)
 
 
 def test_generate_phi_and_z(L, dev):
@@ -128,7 +122,7 @@ def test_generate_phi_and_z(L, dev):
     assert float((phi - O.pupil_from_wavefront(W, 64)).abs().max()) < TOL_PHI
     Z = L.generateZ(1, 3, 64, 0.5, dev).cpu().float()
     Zref = O.zernike_term(1, 3, 64, torch.tensor(0.5))
-    assert int((Z != Zref).sum()) <= 1
+    assert int((Z != Zref).sum()) == 0
 
 
 @pytest.mark.parametrize("key", ["demo_64_ps25", "bern_64_ps25", "lines_64_ps25", "bern_256_ps25", "lines_256_ps25",
@@ -195,4 +189,4 @@ def test_pupil_support_at_large_sizes(golden, L, dev, pn):
         rows = torch.nonzero(nz.any(1)).flatten(); cols = torch.nonzero(nz.any(0)).flatten()
         assert [int(rows[0]), int(rows[-1]), int(cols[0]), int(cols[-1])] == list(g[f"box_{name}_{pn}"])
         sub = phi[::64, ::64].cpu()
-        assert int(((sub - torch.from_numpy(g[f"phisub_{name}_{pn}"])).abs() >= TOL_PHI).sum()) <= 2
+        assert float((sub - torch.from_numpy(g[f"phisub_{name}_{pn}"])).abs().max()) < TOL_PHI

@@ -392,8 +392,11 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
 
     // Through-focus stacks: PC planes are in flight per launch pair.  The fused x-pass gathers the mask-spectrum
     // window of a source point once for all of them (NP = 4 / 2 / 1 planes per workgroup); the y-pass gives every
-    // plane its own groups and slabs.  PC = 4 unless the stack is smaller (measured at 2048^2 x 32 planes).
-    int PC = planes < 4 ? planes : 4;
+    // plane its own groups and slabs.  The cache-resident T budget (~17 items at 2048^2) is shared by the planes in
+    // flight, so more planes mean fewer source points per y-pass accumulator flush.  Measured at 2048^2 x 8 planes
+    // (us per source point and plane): PC = 1 14.2, PC = 2 14.3, PC = 4 15.9 -- the gather was never the x-pass's
+    // limit (its T stores are), so PC = 2: half the gathers at equal speed.  LITHO_ABBE_PLANE_CHUNK overrides.
+    int PC = planes < 2 ? planes : 2;
     if (kn.plane_chunk > 0) PC = kn.plane_chunk < planes ? kn.plane_chunk : planes;
     if (PC > g_cap(pn)) PC = g_cap(pn);
     int G = Gtot / PC;                                         // groups per plane

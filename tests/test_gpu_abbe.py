@@ -245,7 +245,7 @@ def test_config5_stack_at_size_vs_golden(golden, L, dev):
     shifts = torch.from_numpy(g["shifts"]).to(dev)
     raw = L.abbeIntensity(mft, stack, shifts, N)
     plan = nat.last_plan()
-    assert plan["fused_xpass"] == 1 and plan["planes_in_flight"] == 4 and plan["variant"] == 1
+    assert plan["fused_xpass"] == 1 and plan["planes_in_flight"] == 2 and plan["variant"] == 1
     assert raw.shape == (32, pn, pn)
     img = L.postProcess(raw, eps)
     assert tuple(img.shape[1:]) == tuple(g["final_shape"])
@@ -265,10 +265,19 @@ def test_config5_stack_at_size_vs_golden(golden, L, dev):
     for k in (0, 5, 18, 31):
         one = L.abbeIntensity(mft, stack[k], shifts, N).cpu()
         assert rel_max(raw[k], one) < 1e-6, k
-    # stacks that are not a multiple of 4 planes (NP = 2 and NP = 1 launches) and the plane-chunk knob
+    # an odd stack (a last chunk of one plane) and NP = 4 launches through the plane-chunk knob
     part = L.abbeIntensity(mft, stack[4:11], shifts, N).cpu()
     for j in range(7):
         assert rel_max(part[j], raw[4 + j]) < 1e-6, j
+    import os
+    os.environ["LITHO_ABBE_PLANE_CHUNK"] = "4"
+    try:
+        four = L.abbeIntensity(mft, stack[8:16], shifts, N).cpu()
+        assert nat.last_plan()["planes_in_flight"] == 4
+    finally:
+        del os.environ["LITHO_ABBE_PLANE_CHUNK"]
+    for j in range(8):
+        assert rel_max(four[j], raw[8 + j]) < 1e-6, j
 
 
 def test_stack_plane_chunk_knob_and_generic_variant(L, dev, monkeypatch):

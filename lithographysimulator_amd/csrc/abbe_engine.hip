@@ -214,7 +214,7 @@ static int env_int(const char* name, int dflt)
 
 // Tuning / test knobs.  Read ONCE per C-ABI call (the parity tests flip them between calls), never per launch.
 struct Knobs {
-    int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk, xsplit;
+    int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk, xsplit, rect;
     static Knobs read()
     {
         Knobs k;
@@ -229,6 +229,7 @@ struct Knobs {
         k.w64x = env_int("LITHO_ABBE_W64X", 0);
         k.plane_chunk = env_int("LITHO_ABBE_PLANE_CHUNK", 0);
         k.xsplit = env_int("LITHO_ABBE_XSPLIT", 1);
+        k.rect = env_int("LITHO_ABBE_RECT", 1);
         return k;
     }
 };
@@ -301,7 +302,7 @@ static void make_geom(PassGeom& g, int pn, int N, int r0, int c0, int h, int wdt
     g.pn = pn; g.c = pn / 2; g.N = N; g.nt = (pn + 3) / 4;
     g.kx0 = c0 - g.c; g.kx1 = c0 + wdt - g.c;
     g.ky0 = r0 - g.c; g.ky1 = r0 + h - g.c;
-    g.rows = h; g.general = general;
+    g.rows = h; g.general = general; g.rect_off = 0;
     g.xmask = slot_mask(N, g.kx0, g.kx1);
     g.ymask = slot_mask(N, g.ky0, g.ky1);
     set_tile(g, h, tile_cols);
@@ -376,13 +377,15 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     // radix-16 y-pass does not (measured in round 1), so: 8 columns on the wave path, 4 elsewhere.
     if (kn.tile <= 0 && variant == 1 && w64_shape && !kn.w64x) set_tile(g, h, 8);
     const bool use_w64 = variant == 1 && w64_shape && (g.tcl == 2 || g.tcl == 3);
-    const int wave_cols = N == 1024 ? 8 : (N == 8192 ? 2 : 4);        // columns per wave-kernel workgroup
+    g.rect_off = kn.rect ? 0 : 1;
+    const bool rect = N == 2048 && !g.rect_off;                       // k_ypass_rect: two columns per wave
+    const int wave_cols = (N == 1024 || rect) ? 8 : (N == 8192 ? 2 : 4);        // columns per wave-kernel workgroup
     const int tc = 1 << g.tcl;
     const int wave_wpt = tc > wave_cols ? tc / wave_cols : 1;         // workgroups that share one T tile
     const int tile_blocks = !use_w64 ? (g.nt + lines_per_wg - 1) / lines_per_wg
                             : wave_wpt == 1 ? (pn + wave_cols - 1) / wave_cols
                                             : wave_wpt * (((pn + tc - 1) / tc + 7) / 8 * 8);
-    const int resident = 256 * (use_w64 ? (N <= 2048 ? 4 : 2) : l2n <= 12 ? 3 : (l2n == 13 ? 2 : 1));
+    const int resident = 256 * (use_w64 ? ((N <= 2048 && !rect) ? 4 : 2) : l2n <= 12 ? 3 : (l2n == 13 ? 2 : 1));
     int a_ = tile_blocks, b_ = resident;
     while (b_) { const int t_ = a_ % b_; a_ = b_; b_ = t_; }
     int Gtot = resident / a_;                                  // groups that fill whole rounds
@@ -562,7 +565,7 @@ static int mask_spectrum(const int16_t* geo, int pn, double eps, int N, float2* 
     g.pn = pn; g.c = pn / 2; g.N = N; g.nt = (int)nt;
     g.kx0 = j0 - N / 2; g.kx1 = j1 - N / 2;
     g.ky0 = g.kx0; g.ky1 = g.kx1;
-    g.rows = j1 - j0; g.general = 0;
+    g.rows = j1 - j0; g.general = 0; g.rect_off = 0;
     g.xmask = slot_mask(N, g.kx0, g.kx1);
     g.ymask = slot_mask(N, g.ky0, g.ky1);
     set_tile(g, g.rows);

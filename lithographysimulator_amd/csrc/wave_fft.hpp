@@ -65,6 +65,32 @@ __device__ __forceinline__ float2 mul_root128(float2 v)
     }
 }
 
+// In-place P-point radix-2 DIF network (P = 2^LP) on x[OFF .. OFF + P): x[OFF + brev_LP(k)] <- sum_j x[OFF + j] w_P^(j k)
+template <int LP, int OFF, int TOTAL>
+__device__ __forceinline__ void dif_network(float2 (&x)[TOTAL])
+{
+    constexpr int P = 1 << LP;
+    static_for<0, LP>([&](auto s_) {
+        constexpr int s = decltype(s_)::value;
+        constexpr int half = (P / 2) >> s;            // butterfly span
+        constexpr int stride = (64 / P) << s;         // twiddle step in 64ths
+        static_for<0, P / 2>([&](auto b_) {
+            constexpr int b = decltype(b_)::value;
+            constexpr int grp = b / half, i = b % half;
+            constexpr int lo = OFF + grp * 2 * half + i, hi = lo + half;
+            const float2 a = x[lo], c = x[hi];
+            x[lo] = cadd(a, c);
+            x[hi] = mul_root64<(i * stride) % 32>(csub(a, c));
+        });
+    });
+}
+__host__ __device__ constexpr int brev_bits(int v, int bits)
+{
+    int r = 0;
+    for (int b = 0; b < bits; ++b) r |= ((v >> b) & 1) << (bits - 1 - b);
+    return r;
+}
+
 template <int LS>
 struct WaveSq {
     static_assert(LS == 5 || LS == 6, "S = 32 or 64");
@@ -144,6 +170,50 @@ struct WaveSq {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         dft_dif(x);                                    // slot brev(k2) = X[l + S k2]
+    }
+
+    // ------------------------------------------------------------------------------------------------
+    // TWO (S*S/2)-point lines per wave, rectangular split N = S lanes x S/2 slots (N = 2048 for S = 64):
+    //   X[m + (S/2) k2] = sum_l wS^(l k2) [ w_N^(l m) sum_j x[l + S j] w_{S/2}^(j m) ],   l < S, j, m < S/2, k2 < S.
+    // Slots [0, S/2) hold line 0, slots [S/2, S) line 1 (sample l + S j in slot line*S/2 + j).  Pass A = two
+    // independent S/2-point DIFs over the slots; the S x S transpose is the square kernel's: column c = line*S/2 + m
+    // goes to lane c, which then runs the full S-point pass B over l for ITS (line, m).  On return lane c = (line, m)
+    // holds X_line[m + (S/2) k2] in slot brev(k2).  tw = load_lane_twiddles(table_N, lane, 1) (entries >= 8 + S/16
+    // are unused).  Same register and LDS footprint as run(), but each wave keeps all 64 lanes busy on 2048-point
+    // lines (the S = 32 kernel runs two half-waves with half the pruning).
+    // ------------------------------------------------------------------------------------------------
+    __device__ static __forceinline__ void run_rect2(float2 (&x)[S], const LaneTwiddles& tw, float* lds, int lane)
+    {
+        static_assert(LS == 6, "rectangular two-line transform: S = 64");
+        constexpr int H = S / 2, LH = LS - 1;
+        dif_network<LH, 0, S>(x);
+        dif_network<LH, H, S>(x);                      // slot line*H + brev_LH(m) = Y_line[l, m]
+        static_for<0, S>([&](auto c_) {
+            constexpr int c = decltype(c_)::value;
+            constexpr int m = c & (H - 1), a = m >> 3, b = m & 7, sl = (c & H) + brev_bits(m, LH);
+            if constexpr (b != 0) x[sl] = cmul(x[sl], tw.row[b]);
+            if constexpr (a != 0) x[sl] = cmul(x[sl], tw.row[8 + a]);
+        });
+        float* const wr = lds + lane * (S + 1);
+        float* const rd = lds + lane;
+        auto slot_of = [](int c) constexpr { return (c & H) + brev_bits(c & (H - 1), LH); };
+        static_for<0, S>([&](auto c_) { constexpr int c = decltype(c_)::value; wr[c] = x[slot_of(c)].x; });
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float re[S];
+        static_for<0, S>([&](auto r_) { constexpr int r = decltype(r_)::value; re[r] = rd[r * (S + 1)]; });
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        static_for<0, S>([&](auto c_) { constexpr int c = decltype(c_)::value; wr[c] = x[slot_of(c)].y; });
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        static_for<0, S>([&](auto r_) {
+            constexpr int r = decltype(r_)::value;
+            x[r] = make_float2(re[r], rd[r * (S + 1)]);
+        });
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        dft_dif(x);                                    // slot brev(k2) = X_line[m + H k2]
     }
 
     // ------------------------------------------------------------------------------------------------

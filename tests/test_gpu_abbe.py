@@ -461,6 +461,32 @@ def test_wave_per_line_and_radix16_ypass_agree_2048(L, dev, monkeypatch):
     assert rel_max(wx, part) < 2e-6                     # the (slower, opt-in) wave-per-line x-pass
 
 
+def test_2048_kernels_agree_1024(L, dev, monkeypatch):
+    """BASELINE config 2's size (1024^2, N = 2048).  Default y-pass = k_ypass_rect (two adjacent columns per wave, one
+    16-byte load per row pair); the S = 32 wave kernel and the radix-16 kernel must give the same image, with 4- and
+    8-column T tiles, also for a stack."""
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    pn = 1024
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    pf = L.Pupil(pn, WL, NA, f16(DEMO_AB), dev).generatePupilFunction()
+    sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateAnnular(), pn)
+    sel = sh[(torch.arange(75, device=dev) * sh.shape[0]) // 75]
+    ref = L.abbeIntensity(mft, pf, sel, N).cpu()
+    for env in ({"LITHO_ABBE_RECT": "0"}, {"LITHO_ABBE_W64": "0"}, {"LITHO_ABBE_TILE": "4"},
+                {"LITHO_ABBE_TILE": "4", "LITHO_ABBE_RECT": "0"}, {"LITHO_ABBE_GROUPS": "3", "LITHO_ABBE_BATCH": "10"}):
+        got = _with_env(monkeypatch, L, env, lambda: L.abbeIntensity(mft, pf, sel, N).cpu())
+        assert rel_max(got, ref) < 2e-6, env
+    o = O()
+    chain = o.abbe_raw(mft.cpu(), pf.cpu(), sel[:6].cpu(), N)
+    assert rel_max(L.abbeIntensity(mft, pf, sel[:6], N).cpu(), chain) < TOL_IMAGE_MAX
+    stack = L.throughFocusPupils(pn, WL, NA, f16(DEMO_AB), [-90.0, 30.0, 110.0], dev)
+    both = L.abbeIntensity(mft, stack, sel[:9], N).cpu()
+    for k in range(3):
+        assert rel_max(both[k], L.abbeIntensity(mft, stack[k], sel[:9], N).cpu()) < 1e-6
+
+
 def test_8192_kernels_agree_4096(L, dev, monkeypatch):
     """BASELINE config 4's size (4096^2, N = 8192).  Default = k_xpass_split (each row as two 4096-point transforms,
     16-byte T stores) + k_ypass_pair (a pair of waves per column).  The 8192-point radix-16 engine kernels they

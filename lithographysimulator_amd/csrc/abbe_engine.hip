@@ -368,19 +368,23 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     // count that makes it a whole number of full-occupancy rounds (256 CUs x workgroups per CU).
     const int l2n = ilog2(N);
     const int lines_per_wg = (N / 16 >= 64) ? 1 : 64 / (N / 16);
-    // wave-per-line y-pass (k_ypass_wave): N = 2 pn with pn = 512, 1024, 2048; pn = 4096: pair-of-waves kernel (k_ypass_pair)
-    const bool w64_ok = (pn * 2 == N) && (N == 1024 || N == 2048 || N == 4096 || (N == 8192 && kn.w64_8192));   // w64_8192 defaults to 1
+    // wave-level y-pass kernels, N = 2 pn: N = 512, 1024, 2048 k_ypass_rect (8, 4, 2 columns per wave; fall-back
+    // k_ypass_wave with S = 32 for 1024 and 2048), N = 4096 k_ypass_wave (S = 64), N = 8192 k_ypass_pair
+    const bool rect_ok = kn.rect && (N == 2048 || N == 1024 || (N == 512 && (kn.tile <= 0 || kn.tile == 8)));
+    const bool w64_ok = (pn * 2 == N) && ((N == 512 && rect_ok) || N == 1024 || N == 2048 || N == 4096 ||
+                                          (N == 8192 && kn.w64_8192));   // w64_8192 defaults to 1
     const bool w64_shape = w64_ok && kn.w64;
     // T tile width.  The x-pass's T stores are bound by the memory system's rate for partial-line writes: measured
     // (scripts/ubench/write_bw.hip) 2.2 TB/s for 32-byte granules (4-column tiles), 3.4 TB/s for 64-byte granules
     // (8 columns), 5.2 TB/s for whole 128-byte lines.  The wave kernels read 8-column tiles at no extra cost, the
     // radix-16 y-pass does not (measured in round 1), so: 8 columns on the wave path, 4 elsewhere.
     if (kn.tile <= 0 && variant == 1 && w64_shape && !kn.w64x) set_tile(g, h, 8);
-    const bool use_w64 = variant == 1 && w64_shape && (g.tcl == 2 || g.tcl == 3);
-    g.rect_off = kn.rect ? 0 : 1;
-    const bool rect = N == 2048 && !g.rect_off;                       // k_ypass_rect: two columns per wave
-    const int wave_cols = (N == 1024 || rect) ? 8 : (N == 8192 ? 2 : 4);        // columns per wave-kernel workgroup
     const int tc = 1 << g.tcl;
+    // k_ypass_rect: 4096 / N adjacent columns per wave (they must fit one T tile)
+    const bool rect = rect_ok && N <= 2048 && (4096 / N) <= tc;
+    g.rect_off = rect ? 0 : 1;
+    const bool use_w64 = variant == 1 && w64_shape && (g.tcl == 2 || g.tcl == 3) && (N != 512 || rect);
+    const int wave_cols = rect ? 4 * (4096 / N) : N == 1024 ? 8 : (N == 8192 ? 2 : 4);   // columns per wave-kernel workgroup
     const int wave_wpt = tc > wave_cols ? tc / wave_cols : 1;         // workgroups that share one T tile
     const int tile_blocks = !use_w64 ? (g.nt + lines_per_wg - 1) / lines_per_wg
                             : wave_wpt == 1 ? (pn + wave_cols - 1) / wave_cols

@@ -801,9 +801,9 @@ __global__ __launch_bounds__(256, 2) void k_ypass_pair(
 }
 
 // ----------------------------------------------------------------------------------
-// y-pass for N = 2048, pn = 1024 (BASELINE config 2), pupil inside the unit disk: TWO adjacent columns per wave
-// (WaveSq<6>::run_rect2: 64 lanes x 32 slots per line).  One 16-byte load fetches a row of both columns; workgroup =
-// 4 waves = 8 columns.
+// y-pass for N = 512, 1024, 2048 with pn = N/2 (BASELINE configs 1 and 2), pupil inside the unit disk: NL = 8, 4, 2
+// ADJACENT columns per wave (WaveSq<6>::run_rect: 64 lanes x 64/NL slots per line).  A row of the NL columns is
+// 8 NL contiguous bytes of a T tile: NL/2 16-byte loads.  Workgroup = 4 waves = 4 NL columns.
 // ----------------------------------------------------------------------------------
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 template <int LOG2N, int TC>
@@ -811,10 +811,11 @@ __global__ __launch_bounds__(256, 2) void k_ypass_rect(
     const float2* __restrict__ Tbuf, float* __restrict__ slab, const float2* __restrict__ twtab,
     PassGeom g, int nb, int G, int gstride)
 {
-    static_assert(LOG2N == 11, "two-columns-per-wave y-pass: N = 2048");
+    static_assert(LOG2N >= 9 && LOG2N <= 11, "multi-column-per-wave y-pass: N = 512, 1024, 2048");
     static_assert(TC == 4 || TC == 8, "T tiles are 4 or 8 columns wide");
     using W = WaveSq<6>;
-    constexpr int S = 64, H = 32, N = 1 << LOG2N;
+    constexpr int S = 64, N = 1 << LOG2N, NL = (S * S) / N, H = S / NL, JL = H / 4;
+    static_assert(NL <= TC, "the wave's columns must sit in one T tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);
     const int lane = threadIdx.x & 63;
@@ -823,7 +824,7 @@ __global__ __launch_bounds__(256, 2) void k_ypass_rect(
     typename W::LaneTwiddles tw;
     W::load_lane_twiddles(tw, twtab, lane, 1);
 
-    const int qx0 = wave_first_column<TC, 8>(blockIdx.x) + 2 * wv;       // even: the pair (qx0, qx0 + 1) sits in one tile
+    const int qx0 = wave_first_column<TC, 4 * NL>(blockIdx.x) + NL * wv;  // multiple of NL: the wave's columns sit in one tile
     const int tile = qx0 / TC, col = qx0 & (TC - 1);
     const int plane = blockIdx.y / G, grp = blockIdx.y - plane * G;      // see k_ypass_acc
     Tbuf += (size_t)plane * nb * g.t_point;
@@ -832,11 +833,11 @@ __global__ __launch_bounds__(256, 2) void k_ypass_rect(
     float acc[S / 2];
     static_for<0, S / 2>([&](auto i) { acc[i] = 0.f; });
 
-    // slot j (of either line) <-> sample n = lane + 64 j: k = n for j <= 8, k = n - N for j >= 24; T row a = k - ky0
+    // slot j (of every line) <-> sample n = lane + 64 j: k = n for j <= JL, k = n - N for j >= H - JL; T row a = k - ky0
     constexpr int RB = 8 * TC;
     const unsigned tile_bytes = active ? (unsigned)g.rows * RB : 0u;
     const unsigned vb = (unsigned)(lane - g.ky0) * RB + (unsigned)col * 8u;
-    auto slot_off = [&](int j) { return vb + (unsigned)(j <= 8 ? RB * S * j : RB * S * j - RB * N); };
+    auto slot_off = [&](int j) { return vb + (unsigned)(j <= JL ? RB * S * j : RB * S * j - RB * N); };
 
     for (int s = grp; s < nb; s += G) {
         const __amdgpu_buffer_rsrc_t rT =
@@ -844,16 +845,19 @@ __global__ __launch_bounds__(256, 2) void k_ypass_rect(
         float2 x[S];
         static_for<0, H>([&](auto j_) {
             constexpr int j = decltype(j_)::value;
-            if constexpr (j <= 8 || j >= H - 8) {
-                const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(rT, slot_off(j), 0, 0);
-                x[j] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));          // column qx0
-                x[H + j] = make_float2(__uint_as_float(v.z), __uint_as_float(v.w));      // column qx0 + 1
-            } else {
-                x[j] = make_float2(0.f, 0.f);
-                x[H + j] = make_float2(0.f, 0.f);
-            }
+            static_for<0, NL / 2>([&](auto q_) {
+                constexpr int q = decltype(q_)::value;
+                if constexpr (j <= JL || j >= H - JL) {
+                    const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(rT, slot_off(j) + 16u * q, 0, 0);
+                    x[(2 * q) * H + j] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));          // column qx0 + 2q
+                    x[(2 * q + 1) * H + j] = make_float2(__uint_as_float(v.z), __uint_as_float(v.w));      // column qx0 + 2q + 1
+                } else {
+                    x[(2 * q) * H + j] = make_float2(0.f, 0.f);
+                    x[(2 * q + 1) * H + j] = make_float2(0.f, 0.f);
+                }
+            });
         });
-        W::run_rect2(x, tw, lds, lane);
+        W::template run_rect<NL>(x, tw, lds, lane);
         static_for<0, S / 2>([&](auto i_) {
             constexpr int i = decltype(i_)::value;
             constexpr int k2 = i < S / 4 ? i : S / 2 + i;
@@ -862,13 +866,13 @@ __global__ __launch_bounds__(256, 2) void k_ypass_rect(
         });
     }
 
-    const int qx = qx0 + (lane >> 5), m = lane & (H - 1);
+    const int qx = qx0 + lane / H, m = lane & (H - 1);
     if (!active || qx >= g.pn) return;
     float* srow = slab + ((size_t)grp * g.nt * 4 + qx) * g.pn;
     static_for<0, S / 2>([&](auto i_) {
         constexpr int i = decltype(i_)::value;
         constexpr int k2 = i < S / 4 ? i : S / 2 + i;
-        constexpr int ubase = k2 < S / 2 ? H * k2 : H * k2 - N;             // bin u = m + 32 k2 (mod N, centred)
+        constexpr int ubase = k2 < S / 2 ? H * k2 : H * k2 - N;             // bin u = m + H k2 (mod N, centred)
         srow[ubase + m + g.c] += acc[i];
     });
 }
@@ -1087,25 +1091,32 @@ struct SizeImpl {
             hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, 2>(g.pn), planes * G), dim3(256), lds, st, T, slab, tw, g, nb, G,
                                gstride);
             return hipGetLastError();
-        } else if constexpr (LOG2N == 11) {
-            if (!g.rect_off) {
-                static LdsOnce once;
-                constexpr size_t lds = 4 * WaveSq<6>::LDS_FLOATS * sizeof(float);
-                auto kern = k_ypass_rect<LOG2N, TC>;
-                hipError_t e = set_lds(once, kern, lds);
-                if (e != hipSuccess) return e;
-                hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, 8>(g.pn), planes * G), dim3(256), lds, st, T, slab, tw, g, nb,
-                                   G, gstride);
-                return hipGetLastError();
+        } else if constexpr (LOG2N >= 9 && LOG2N <= 11) {
+            constexpr int NL = 4096 >> LOG2N;                       // columns per wave of k_ypass_rect
+            if constexpr (NL <= TC) {
+                if (!g.rect_off) {
+                    static LdsOnce once;
+                    constexpr size_t lds = 4 * WaveSq<6>::LDS_FLOATS * sizeof(float);
+                    auto kern = k_ypass_rect<LOG2N, TC>;
+                    hipError_t e = set_lds(once, kern, lds);
+                    if (e != hipSuccess) return e;
+                    hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, 4 * NL>(g.pn), planes * G), dim3(256), lds, st, T, slab, tw,
+                                       g, nb, G, gstride);
+                    return hipGetLastError();
+                }
             }
-            static LdsOnce once;
-            using WS = WaveShape<LOG2N>;
-            auto kern = k_ypass_wave<LOG2N, TC>;
-            hipError_t e = set_lds(once, kern, WS::LDS_BYTES);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, WS::COLS>(g.pn), planes * G), dim3(WS::THREADS), WS::LDS_BYTES,
-                               st, T, slab, tw, g, nb, G, gstride);
-            return hipGetLastError();
+            if constexpr (LOG2N >= 10) {
+                static LdsOnce once;
+                using WS = WaveShape<LOG2N>;
+                auto kern = k_ypass_wave<LOG2N, TC>;
+                hipError_t e = set_lds(once, kern, WS::LDS_BYTES);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, WS::COLS>(g.pn), planes * G), dim3(WS::THREADS),
+                                   WS::LDS_BYTES, st, T, slab, tw, g, nb, G, gstride);
+                return hipGetLastError();
+            } else {
+                return hipErrorNotSupported;
+            }
         } else if constexpr (LOG2N >= 10 && LOG2N <= 12) {
             static LdsOnce once;
             using WS = WaveShape<LOG2N>;

@@ -173,30 +173,30 @@ struct WaveSq {
     }
 
     // ------------------------------------------------------------------------------------------------
-    // TWO (S*S/2)-point lines per wave, rectangular split N = S lanes x S/2 slots (N = 2048 for S = 64):
-    //   X[m + (S/2) k2] = sum_l wS^(l k2) [ w_N^(l m) sum_j x[l + S j] w_{S/2}^(j m) ],   l < S, j, m < S/2, k2 < S.
-    // Slots [0, S/2) hold line 0, slots [S/2, S) line 1 (sample l + S j in slot line*S/2 + j).  Pass A = two
-    // independent S/2-point DIFs over the slots; the S x S transpose is the square kernel's: column c = line*S/2 + m
-    // goes to lane c, which then runs the full S-point pass B over l for ITS (line, m).  On return lane c = (line, m)
-    // holds X_line[m + (S/2) k2] in slot brev(k2).  tw = load_lane_twiddles(table_N, lane, 1) (entries >= 8 + S/16
-    // are unused).  Same register and LDS footprint as run(), but each wave keeps all 64 lanes busy on 2048-point
-    // lines (the S = 32 kernel runs two half-waves with half the pruning).
+    // NL = 2, 4 or 8 lines of N = S*S/NL points per wave, rectangular split N = S lanes x H slots (H = S / NL;
+    // N = 2048, 1024, 512 for S = 64):
+    //   X[m + H k2] = sum_l wS^(l k2) [ w_N^(l m) sum_j x[l + S j] w_H^(j m) ],   l < S, j, m < H, k2 < S.
+    // Slots [line*H, line*H + H) hold line `line` (sample l + S j in slot line*H + j).  Pass A = NL independent
+    // H-point DIFs over the slots; the S x S transpose is the square kernel's: column c = line*H + m goes to lane c,
+    // which then runs the full S-point pass B over l for ITS (line, m).  On return lane c = (line, m) holds
+    // X_line[m + H k2] in slot brev(k2).  tw = load_lane_twiddles(table_N, lane, 1) (entries >= 8 + H/8 are unused).
+    // Same register and LDS footprint as run(), and all 64 lanes stay busy on short lines.
     // ------------------------------------------------------------------------------------------------
-    __device__ static __forceinline__ void run_rect2(float2 (&x)[S], const LaneTwiddles& tw, float* lds, int lane)
+    template <int NL>
+    __device__ static __forceinline__ void run_rect(float2 (&x)[S], const LaneTwiddles& tw, float* lds, int lane)
     {
-        static_assert(LS == 6, "rectangular two-line transform: S = 64");
-        constexpr int H = S / 2, LH = LS - 1;
-        dif_network<LH, 0, S>(x);
-        dif_network<LH, H, S>(x);                      // slot line*H + brev_LH(m) = Y_line[l, m]
+        static_assert(LS == 6 && (NL == 2 || NL == 4 || NL == 8), "rectangular multi-line transform: S = 64");
+        constexpr int H = S / NL, LH = LS - (NL == 2 ? 1 : NL == 4 ? 2 : 3);
+        static_for<0, NL>([&](auto q_) { dif_network<LH, decltype(q_)::value * H, S>(x); });   // slot line*H + brev_LH(m) = Y_line[l, m]
+        auto slot_of = [](int c) constexpr { return (c / H) * H + brev_bits(c % H, LH); };
         static_for<0, S>([&](auto c_) {
             constexpr int c = decltype(c_)::value;
-            constexpr int m = c & (H - 1), a = m >> 3, b = m & 7, sl = (c & H) + brev_bits(m, LH);
+            constexpr int m = c % H, a = m >> 3, b = m & 7, sl = (c / H) * H + brev_bits(m, LH);
             if constexpr (b != 0) x[sl] = cmul(x[sl], tw.row[b]);
             if constexpr (a != 0) x[sl] = cmul(x[sl], tw.row[8 + a]);
         });
         float* const wr = lds + lane * (S + 1);
         float* const rd = lds + lane;
-        auto slot_of = [](int c) constexpr { return (c & H) + brev_bits(c & (H - 1), LH); };
         static_for<0, S>([&](auto c_) { constexpr int c = decltype(c_)::value; wr[c] = x[slot_of(c)].x; });
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -487,6 +487,33 @@ def test_2048_kernels_agree_1024(L, dev, monkeypatch):
         assert rel_max(both[k], L.abbeIntensity(mft, stack[k], sel[:9], N).cpu()) < 1e-6
 
 
+@pytest.mark.parametrize("pn", [256, 512])
+def test_small_size_kernels_agree(L, dev, monkeypatch, pn):
+    """N = 512 / 1024 (pn = 256 / 512): default y-pass = k_ypass_rect with 8 / 4 adjacent columns per wave; the
+    radix-16 kernels (and, at N = 1024, the S = 32 wave kernel) must agree, and so must the CPU oracle."""
+    from lithographysimulator_amd import _native as nat
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    pf = L.Pupil(pn, WL, NA, f16(DEMO_AB), dev).generatePupilFunction()
+    sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateQuasar(4, -math.pi / 8), pn)
+    sel = sh[(torch.arange(300, device=dev) * sh.shape[0]) // 300]
+    nat.set_profiling(True)
+    try:
+        ref = L.abbeIntensity(mft, pf, sel, N).cpu()
+        assert nat.last_profile()["ypass_kernel"] == "k_ypass_wave"          # the wave-level family (k_ypass_rect here)
+    finally:
+        nat.set_profiling(False)
+    for env in ({"LITHO_ABBE_RECT": "0"}, {"LITHO_ABBE_W64": "0"}, {"LITHO_ABBE_TILE": "4"}, {"LITHO_ABBE_GROUPS": "5"}):
+        got = _with_env(monkeypatch, L, env, lambda: L.abbeIntensity(mft, pf, sel, N).cpu())
+        assert rel_max(got, ref) < 2e-6, env
+    o = O()
+    chain = o.abbe_raw(mft.cpu(), pf.cpu(), sel[:40].cpu(), N)
+    got = L.abbeIntensity(mft, pf, sel[:40], N).cpu()
+    assert rel_max(got, chain) < TOL_IMAGE_MAX and rel_l2(got, chain) < TOL_IMAGE_L2
+
+
 def test_8192_kernels_agree_4096(L, dev, monkeypatch):
     """BASELINE config 4's size (4096^2, N = 8192).  Default = k_xpass_split (each row as two 4096-point transforms,
     16-byte T stores) + k_ypass_pair (a pair of waves per column).  The 8192-point radix-16 engine kernels they

@@ -127,7 +127,7 @@ int litho_mask_spectrum(const int16_t *geometry, int pn, double epsilon, int N, 
 int litho_abbe_last_plan(int64_t fields_host[12]);
 
 /* ---- Per-kernel timing for bench.py: when on, litho_abbe_accumulate brackets every x-pass
- * and y-pass launch with HIP events recorded on `stream` (at most 4096 launches per call)
+ * and y-pass launch with HIP events recorded on `stream` (the first 4096 launch pairs of a call)
  * and waits for the last one before returning.  fields: [0]=x-pass total ms, [1]=x-pass
  * batches (one batch = the x-pass launches of one launch pair), [2]=T items (source point x plane) they
  * covered, [3..5]=the same for the y-pass, [6]=1 when the y-pass ran the wave-per-line kernel

@@ -87,3 +87,18 @@ def test_pupil_length_4_is_an_index_error_before_any_gpu_work(nat):
     # J == 4 is rejected on the host (pupil.py:91-92 indexes [4]); no device is touched
     coeffs = (ctypes.c_uint16 * 4)(0, 0, 0, 0x3C00)
     assert nat.lib().litho_pupil(coeffs, 4, 64, 0.7, 193.0, 0, None, ctypes.c_void_p(8), None) == nat.E_INDEX
+
+
+def test_diag_switches_do_not_compile_into_the_product():
+    """LITHO_DIAG_* switches remove loads / stores / barriers from the kernels (timing diagnostics, wrong results).
+    A stray -D in a product build must fail to compile; only LITHO_DIAG_BUILD (scripts/build_variants.sh, separate
+    output, library reports "gfx950-diag") may carry them."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(ROOT, "lithographysimulator_amd", "csrc", "inst_04.hip")
+    base = [hipcc, "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "--cuda-host-only", src]
+    bad = subprocess.run(base + ["-DLITHO_DIAG_XNOSTORE"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "LITHO_DIAG_" in bad.stderr
+    ok = subprocess.run(base + ["-DLITHO_DIAG_XNOSTORE", "-DLITHO_DIAG_BUILD"], capture_output=True, text=True)
+    assert ok.returncode == 0, ok.stderr[-1500:]

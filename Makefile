@@ -8,14 +8,22 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-functi
 # No SLP packing: v_pk_*_f32 are not faster than two scalar ops on gfx950 and cost ~100 register moves
 # per transform (and 40-80 VGPRs).
 FFTFLAGS := -fno-signed-zeros -fno-slp-vectorize
+# Wave-level y-pass kernels live in their own translation units (instw_*.hip) so that they can take their own
+# scheduling strategy.  Same-box A/B (us per source point, default vs max-ilp): N = 4096 (k_ypass_wave) 9.21 -> 9.03,
+# N = 2048 1.82 -> 1.80, N = 8192 (k_ypass_pair, barriers) 46.6 -> 51.4: max-ilp for N = 4096 only.
+WAVEFLAGS_12 ?= -mllvm -amdgpu-sched-strategy=max-ilp
 INST := $(patsubst $(CSRC)/%.hip,build/%.o,$(wildcard $(CSRC)/inst_*.hip))
-HDRS := $(CSRC)/fft_core.hpp $(CSRC)/wave_fft.hpp $(CSRC)/engine_kernels.hpp $(CSRC)/engine_common.hpp include/litho_abbe.h
+INSTW := $(patsubst $(CSRC)/%.hip,build/%.o,$(wildcard $(CSRC)/instw_*.hip))
+HDRS := $(CSRC)/fft_core.hpp $(CSRC)/wave_fft.hpp $(CSRC)/engine_kernels.hpp $(CSRC)/wave_kernels.hpp $(CSRC)/engine_common.hpp include/litho_abbe.h
 
 all: $(OUT) oracle
 
 build/inst_%.o: $(CSRC)/inst_%.hip $(HDRS)
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) $(FFTFLAGS) -c $< -o $@
+build/instw_%.o: $(CSRC)/instw_%.hip $(HDRS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) $(FFTFLAGS) $(WAVEFLAGS_$*) -c $< -o $@
 build/abbe_engine.o: $(CSRC)/abbe_engine.hip $(HDRS)
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -25,7 +33,7 @@ build/optics.o: $(CSRC)/optics.hip $(CSRC)/engine_common.hpp include/litho_abbe.
 build/common.o: $(CSRC)/common.hip $(CSRC)/engine_common.hpp include/litho_abbe.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-$(OUT): build/abbe_engine.o build/optics.o build/common.o $(INST)
+$(OUT): build/abbe_engine.o build/optics.o build/common.o $(INST) $(INSTW)
 	@mkdir -p lithographysimulator_amd/lib
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 

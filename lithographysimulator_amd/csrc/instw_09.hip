@@ -1,0 +1,5 @@
+// instw_09.hip -- wave-level y-pass kernels for FFT size N = 512 (own translation unit: max-ILP scheduling).
+#include "wave_kernels.hpp"
+namespace litho {
+LITHO_DEFINE_WAVE_OPS(9)
+}

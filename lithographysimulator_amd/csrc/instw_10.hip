@@ -1,0 +1,5 @@
+// instw_10.hip -- wave-level y-pass kernels for FFT size N = 1024 (own translation unit: max-ILP scheduling).
+#include "wave_kernels.hpp"
+namespace litho {
+LITHO_DEFINE_WAVE_OPS(10)
+}

@@ -1,0 +1,5 @@
+// instw_12.hip -- wave-level y-pass kernels for FFT size N = 4096 (own translation unit: max-ILP scheduling).
+#include "wave_kernels.hpp"
+namespace litho {
+LITHO_DEFINE_WAVE_OPS(12)
+}

@@ -1,0 +1,357 @@
+// wave_kernels.hpp -- the wave-level y-pass kernels (one wavefront, a pair of wavefronts, or several columns per
+// wavefront) and their launcher.  Included ONLY by instw_*.hip: these translation units can take their own
+// scheduling strategy (Makefile: max-ilp for N = 4096, 2 % faster there; the pair kernel and the workgroup-level
+// FFT kernels prefer the default), so the kernels must not be instantiated anywhere else.
+#pragma once
+#include "engine_kernels.hpp"
+
+namespace litho {
+
+// ----------------------------------------------------------------------------------
+// y-pass, wave-per-line variant (wave_fft.hpp) for N = S*S*D, pn = N/2, pupil inside the unit disk:
+//   N = 1024: S = 32, D = 1     N = 2048: S = 32, D = 2     N = 4096: S = 64, D = 1     N = 8192: S = 64, D = 2
+// A "unit" is one S*S-point sub-transform, computed by S lanes on their own: no workgroup barriers, half
+// the LDS traffic of the radix-16 engine.  D = 1: one unit per column.  D = 2: decimation in frequency,
+//   out[2v + p] = sum_n' ([x[n'] + (-1)^p x[n' + N/2]] w_N^(n' p)) w_{N/2}^(n' v),
+// i.e. two independent sub-transforms (even / odd bins) per column; the pruned input makes the first
+// butterfly trivial (at most one of x[n'], x[n'+N/2] is non-zero) and the two units never exchange data.
+// Every consumer of a 4-column T tile sits in the same workgroup.
+// ----------------------------------------------------------------------------------
+template <int LOG2N>
+struct WaveShape {
+    static_assert(LOG2N >= 10 && LOG2N <= 12, "wave-per-line y-pass: N = 1024 .. 4096 (N = 8192: k_ypass_pair)");
+    static constexpr int LS = LOG2N / 2;                     // 5, 5, 6, 6
+    static constexpr int D = 1 << (LOG2N - 2 * LS);          // 1, 2, 1, 2
+    using W = WaveSq<LS>;
+    static constexpr int S = W::S;
+    // (one 512-thread workgroup per 8-column tile, so that every consumer of a 64-byte row granule sits on one CU,
+    // was measured slower at 2048^2: y-pass 10.0 vs 9.5 us/point)
+    static constexpr int THREADS = 256;
+    static constexpr int UNITS = THREADS / S;                // sub-transforms per workgroup
+    static constexpr int COLS = UNITS / D;                   // columns per workgroup (4 or 8)
+    static constexpr int TILES = COLS / 4;                   // T tiles per workgroup
+    static constexpr int JLIVE = S * D / 8;                  // live slots: j in [0, JLIVE] and [S - JLIVE, S)
+    static constexpr size_t LDS_BYTES = (size_t)(THREADS / 64) * W::LDS_FLOATS * sizeof(float);
+#ifndef LITHO_WAVE32_MINWAVES
+#define LITHO_WAVE32_MINWAVES 4
+#endif
+    static constexpr int MINWAVES = LS == 5 ? LITHO_WAVE32_MINWAVES : 2;   // S = 32 needs few registers: 4 workgroups per CU
+};
+
+// Block index -> first column of the workgroup.  A workgroup covers COLS columns of T tiles that are TC columns wide;
+// when a tile is shared by WPT = TC / COLS workgroups these are blocks b, b + 8, ... (same XCD, back to back), so the
+// tile's granules are served by one L2.  The grid must have wave_grid_x<TC, COLS>(pn) blocks.
+template <int TC, int COLS>
+__device__ __forceinline__ int wave_first_column(int b)
+{
+    constexpr int WPT = TC > COLS ? TC / COLS : 1;
+    if constexpr (WPT == 1) return b * COLS;
+    else return (((b / (8 * WPT)) * 8 + (b & 7)) * TC) + ((b >> 3) % WPT) * COLS;
+}
+template <int TC, int COLS>
+static inline int wave_grid_x(int pn)
+{
+    constexpr int WPT = TC > COLS ? TC / COLS : 1;
+    if constexpr (WPT == 1) return (pn + COLS - 1) / COLS;
+    else return WPT * (((pn + TC - 1) / TC + 7) / 8 * 8);
+}
+
+template <int LOG2N, int TC>
+__global__ __launch_bounds__(WaveShape<LOG2N>::THREADS, WaveShape<LOG2N>::MINWAVES) void k_ypass_wave(
+    const float2* __restrict__ Tbuf, float* __restrict__ slab, const float2* __restrict__ twtab,
+    PassGeom g, int nb, int G, int gstride)
+{
+    static_assert(TC == 4 || TC == 8, "T tiles are 4 or 8 columns wide");
+    using WS = WaveShape<LOG2N>;
+    using W = typename WS::W;
+    constexpr int S = WS::S, D = WS::D, JLIVE = WS::JLIVE, N = 1 << LOG2N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l = lane & (S - 1);                            // lane inside its unit
+    const int unit = wv * W::LINES + (lane >> WS::LS);
+    const int p = unit % D;                                  // residue of the output bins this unit makes
+    const int colg = unit / D;                               // column inside the workgroup's column group
+    float* lds = smem + wv * W::LDS_FLOATS;
+    typename W::LaneTwiddles tw;
+    W::load_lane_twiddles(tw, twtab, l, D);                  // w_{S*S}^e is entry D*e of the w_N table
+    const float2 tl = twtab[l * p];                          // w_N^(l p)  (1 for p = 0)
+
+    // The tile index is wave-uniform (a wave's units cover at most one tile); readfirstlane makes that
+    // provable, otherwise every buffer access through the tile's descriptor becomes a waterfall loop.
+    const int qx = wave_first_column<TC, WS::COLS>(blockIdx.x) + colg;
+    const int tile = __builtin_amdgcn_readfirstlane(qx / TC);
+    const int col = qx & (TC - 1);
+    const int plane = blockIdx.y / G, grp = blockIdx.y - plane * G;      // see k_ypass_acc
+    Tbuf += (size_t)plane * nb * g.t_point;
+    slab += (size_t)plane * gstride * g.nt * 4 * g.pn;
+    const bool active = tile * TC < g.pn;
+    float acc[S / 2];
+    static_for<0, S / 2>([&](auto i) { acc[i] = 0.f; });
+
+    // Live input slots j (sub-transform sample n' = l + S j): k = n' for j <= JLIVE, k = n' - S*S for the upper
+    // ones (sample n' + N - S*S of the full line); T row a = k - ky0.  The descriptor is windowed on this tile's
+    // rows ([tile][row][TC] layout, RB = 8 TC bytes per row): the range check is the validity test.
+    constexpr int RB = 8 * TC;
+    const unsigned tile_bytes = active ? (unsigned)g.rows * RB : 0u;
+    const unsigned vb = (unsigned)(l - g.ky0) * RB + (unsigned)col * 8u;
+    auto slot_off = [&](int j) { return vb + (unsigned)(j <= JLIVE ? RB * S * j : RB * S * j - RB * S * S); };
+
+    for (int s = grp; s < nb; s += G) {
+        const __amdgpu_buffer_rsrc_t rT =
+            make_rsrc(Tbuf + (size_t)s * g.t_point + (size_t)(active ? tile : 0) * g.rows * TC, tile_bytes);
+        float2 x[S];
+        static_for<0, S>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            if constexpr (j <= JLIVE || j >= S - JLIVE) {
+                float2 v = buf_load_c64(rT, slot_off(j));
+                if constexpr (D > 1) {
+                    // w_N^(n' p) = w_N^(l p) * w_N^(S j p), and (-1)^p for the upper half (q = 1)
+                    if (p) {
+                        constexpr int e = (S * j) % N;
+                        constexpr double ang = 6.283185307179586476925 * e / N;
+                        constexpr float sgn = (j >= S - JLIVE) ? -1.f : 1.f;
+                        const float2 cj = make_float2(sgn * (float)__builtin_cos(ang), sgn * (float)__builtin_sin(ang));
+                        v = cmul(cmul(v, cj), tl);
+                    }
+                }
+                x[j] = v;
+            } else {
+                x[j] = make_float2(0.f, 0.f);
+            }
+        });
+        W::run(x, tw, lds, lane);
+        // kept bins of the sub-transform: v in [-S*S/4, S*S/4)  ->  k2 in [0, S/4) and [3S/4, S)
+        static_for<0, S / 2>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            constexpr int k2 = i < S / 4 ? i : S / 2 + i;
+            const float2 v = x[W::brev(k2)];
+            acc[i] = fmaf(v.x, v.x, fmaf(v.y, v.y, acc[i]));
+        });
+    }
+
+    if (!active || qx >= g.pn) return;
+    float* srow = slab + ((size_t)grp * g.nt * 4 + qx) * g.pn;
+    static_for<0, S / 2>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        constexpr int k2 = i < S / 4 ? i : S / 2 + i;
+        const int n = l + S * k2;
+        const int v = n < S * S / 2 ? n : n - S * S;        // bin of the sub-transform
+        srow[D * v + p + g.c] += acc[i];                    // bin u = D v + p of the full line
+    });
+}
+
+// ----------------------------------------------------------------------------------
+// y-pass for N = 8192, pn = 4096 (BASELINE config 4), pupil inside the unit disk: a PAIR of waves per column
+// (WaveSq<6>::run_pair).  Each wave loads 17 live slots (like the 4096-point kernel), runs a pruned-input pass A,
+// exchanges with its partner at the transpose, and accumulates the 32 kept bins of its half of the line.
+// Workgroup = 4 waves = 2 columns; the two workgroups that share a 4-column T tile are blocks b and b + 8 (same
+// XCD, back to back) so the tile's 32-byte granules are served by one L2.
+// ----------------------------------------------------------------------------------
+template <int LOG2N, int TC>
+__global__ __launch_bounds__(256, 2) void k_ypass_pair(
+    const float2* __restrict__ Tbuf, float* __restrict__ slab, const float2* __restrict__ twtab,
+    PassGeom g, int nb, int G, int gstride)
+{
+    static_assert(LOG2N == 13, "pair-of-waves y-pass: N = 8192");
+    using W = WaveSq<6>;
+    constexpr int S = 64, N = 1 << LOG2N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int par = wv & 1, pair = wv >> 1;
+    float* mat_own = smem + wv * W::LDS_FLOATS;
+    const float* mat_other = smem + (wv ^ 1) * W::LDS_FLOATS;
+    typename W::LaneTwiddles tw;
+    W::load_lane_twiddles(tw, twtab, lane + S * par, 1);
+
+    static_assert(TC == 4 || TC == 8, "T tiles are 4 or 8 columns wide");
+    const int qx = wave_first_column<TC, 2>(blockIdx.x) + pair;
+    const int tile = qx / TC, col = qx & (TC - 1);
+    const int plane = blockIdx.y / G, grp = blockIdx.y - plane * G;      // see k_ypass_acc
+    Tbuf += (size_t)plane * nb * g.t_point;
+    slab += (size_t)plane * gstride * g.nt * 4 * g.pn;
+    const bool active = tile * TC < g.pn;
+    float acc[S / 2];
+    static_for<0, S / 2>([&](auto i) { acc[i] = 0.f; });
+
+    // slot j <-> sample n = lane + 64 par + 128 j: k = n for j <= 8, k = n - N for j >= 56; T row a = k - ky0.
+    constexpr int RB = 8 * TC;                                            // bytes per T row inside a tile
+    const unsigned tile_bytes = active ? (unsigned)g.rows * RB : 0u;
+    const unsigned vb = (unsigned)(lane + S * par - g.ky0) * RB + (unsigned)col * 8u;
+    auto slot_off = [&](int j) { return vb + (unsigned)(j <= 8 ? RB * 2 * S * j : RB * 2 * S * j - RB * N); };
+
+    for (int s = grp; s < nb; s += G) {
+        const __amdgpu_buffer_rsrc_t rT =
+            make_rsrc(Tbuf + (size_t)s * g.t_point + (size_t)(active ? tile : 0) * g.rows * TC, tile_bytes);
+        float2 x[S];
+        static_for<0, S>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            if constexpr (j <= 8 || j >= S - 8) x[j] = buf_load_c64(rT, slot_off(j));
+            else x[j] = make_float2(0.f, 0.f);
+        });
+        W::run_pair(x, tw, mat_own, mat_other, lane, par);
+        static_for<0, S / 2>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            constexpr int k2 = i < S / 4 ? i : S / 2 + i;
+            const float2 v = x[W::brev(k2)];
+            acc[i] = fmaf(v.x, v.x, fmaf(v.y, v.y, acc[i]));
+        });
+    }
+
+    if (!active || qx >= g.pn) return;
+    float* srow = slab + ((size_t)grp * g.nt * 4 + qx) * g.pn;
+    static_for<0, S / 2>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        constexpr int k2 = i < S / 4 ? i : S / 2 + i;
+        constexpr int ubase = k2 < S / 2 ? 2 * S * k2 : 2 * S * k2 - N;      // bin u = lane + 64 par + 128 k2 (mod N, centred)
+        srow[ubase + lane + S * par + g.c] += acc[i];
+    });
+}
+
+// ----------------------------------------------------------------------------------
+// y-pass for N = 512, 1024, 2048 with pn = N/2 (BASELINE configs 1 and 2), pupil inside the unit disk: NL = 8, 4, 2
+// ADJACENT columns per wave (WaveSq<6>::run_rect: 64 lanes x 64/NL slots per line).  A row of the NL columns is
+// 8 NL contiguous bytes of a T tile: NL/2 16-byte loads.  Workgroup = 4 waves = 4 NL columns.
+// ----------------------------------------------------------------------------------
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+template <int LOG2N, int TC>
+__global__ __launch_bounds__(256, 2) void k_ypass_rect(
+    const float2* __restrict__ Tbuf, float* __restrict__ slab, const float2* __restrict__ twtab,
+    PassGeom g, int nb, int G, int gstride)
+{
+    static_assert(LOG2N >= 9 && LOG2N <= 11, "multi-column-per-wave y-pass: N = 512, 1024, 2048");
+    static_assert(TC == 4 || TC == 8, "T tiles are 4 or 8 columns wide");
+    using W = WaveSq<6>;
+    constexpr int S = 64, N = 1 << LOG2N, NL = (S * S) / N, H = S / NL, JL = H / 4;
+    static_assert(NL <= TC, "the wave's columns must sit in one T tile");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* lds = smem + wv * W::LDS_FLOATS;
+    typename W::LaneTwiddles tw;
+    W::load_lane_twiddles(tw, twtab, lane, 1);
+
+    const int qx0 = wave_first_column<TC, 4 * NL>(blockIdx.x) + NL * wv;  // multiple of NL: the wave's columns sit in one tile
+    const int tile = qx0 / TC, col = qx0 & (TC - 1);
+    const int plane = blockIdx.y / G, grp = blockIdx.y - plane * G;      // see k_ypass_acc
+    Tbuf += (size_t)plane * nb * g.t_point;
+    slab += (size_t)plane * gstride * g.nt * 4 * g.pn;
+    const bool active = tile * TC < g.pn;
+    float acc[S / 2];
+    static_for<0, S / 2>([&](auto i) { acc[i] = 0.f; });
+
+    // slot j (of every line) <-> sample n = lane + 64 j: k = n for j <= JL, k = n - N for j >= H - JL; T row a = k - ky0
+    constexpr int RB = 8 * TC;
+    const unsigned tile_bytes = active ? (unsigned)g.rows * RB : 0u;
+    const unsigned vb = (unsigned)(lane - g.ky0) * RB + (unsigned)col * 8u;
+    auto slot_off = [&](int j) { return vb + (unsigned)(j <= JL ? RB * S * j : RB * S * j - RB * N); };
+
+    for (int s = grp; s < nb; s += G) {
+        const __amdgpu_buffer_rsrc_t rT =
+            make_rsrc(Tbuf + (size_t)s * g.t_point + (size_t)(active ? tile : 0) * g.rows * TC, tile_bytes);
+        float2 x[S];
+        static_for<0, H>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            static_for<0, NL / 2>([&](auto q_) {
+                constexpr int q = decltype(q_)::value;
+                if constexpr (j <= JL || j >= H - JL) {
+                    const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(rT, slot_off(j) + 16u * q, 0, 0);
+                    x[(2 * q) * H + j] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));          // column qx0 + 2q
+                    x[(2 * q + 1) * H + j] = make_float2(__uint_as_float(v.z), __uint_as_float(v.w));      // column qx0 + 2q + 1
+                } else {
+                    x[(2 * q) * H + j] = make_float2(0.f, 0.f);
+                    x[(2 * q + 1) * H + j] = make_float2(0.f, 0.f);
+                }
+            });
+        });
+        W::template run_rect<NL>(x, tw, lds, lane);
+        static_for<0, S / 2>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            constexpr int k2 = i < S / 4 ? i : S / 2 + i;
+            const float2 v = x[W::brev(k2)];
+            acc[i] = fmaf(v.x, v.x, fmaf(v.y, v.y, acc[i]));
+        });
+    }
+
+    const int qx = qx0 + lane / H, m = lane & (H - 1);
+    if (!active || qx >= g.pn) return;
+    float* srow = slab + ((size_t)grp * g.nt * 4 + qx) * g.pn;
+    static_for<0, S / 2>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        constexpr int k2 = i < S / 4 ? i : S / 2 + i;
+        constexpr int ubase = k2 < S / 2 ? H * k2 : H * k2 - N;             // bin u = m + H k2 (mod N, centred)
+        srow[ubase + m + g.c] += acc[i];
+    });
+}
+
+
+template <int LOG2N, int TC>
+static hipError_t launch_ypass_wave_tc(const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb, int planes, int G,
+                     int gstride, hipStream_t st)
+{
+    if constexpr (LOG2N == 13) {
+        static LdsOnce once;
+        constexpr size_t lds = 4 * WaveSq<6>::LDS_FLOATS * sizeof(float);
+        auto kern = k_ypass_pair<LOG2N, TC>;
+        hipError_t e = set_lds(once, kern, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, 2>(g.pn), planes * G), dim3(256), lds, st, T, slab, tw, g, nb, G,
+                           gstride);
+        return hipGetLastError();
+    } else if constexpr (LOG2N >= 9 && LOG2N <= 11) {
+        constexpr int NL = 4096 >> LOG2N;                       // columns per wave of k_ypass_rect
+        if constexpr (NL <= TC) {
+            if (!g.rect_off) {
+                static LdsOnce once;
+                constexpr size_t lds = 4 * WaveSq<6>::LDS_FLOATS * sizeof(float);
+                auto kern = k_ypass_rect<LOG2N, TC>;
+                hipError_t e = set_lds(once, kern, lds);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, 4 * NL>(g.pn), planes * G), dim3(256), lds, st, T, slab, tw,
+                                   g, nb, G, gstride);
+                return hipGetLastError();
+            }
+        }
+        if constexpr (LOG2N >= 10) {
+            static LdsOnce once;
+            using WS = WaveShape<LOG2N>;
+            auto kern = k_ypass_wave<LOG2N, TC>;
+            hipError_t e = set_lds(once, kern, WS::LDS_BYTES);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, WS::COLS>(g.pn), planes * G), dim3(WS::THREADS),
+                               WS::LDS_BYTES, st, T, slab, tw, g, nb, G, gstride);
+            return hipGetLastError();
+        } else {
+            return hipErrorNotSupported;
+        }
+    } else if constexpr (LOG2N >= 10 && LOG2N <= 12) {
+        static LdsOnce once;
+        using WS = WaveShape<LOG2N>;
+        auto kern = k_ypass_wave<LOG2N, TC>;
+        hipError_t e = set_lds(once, kern, WS::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, WS::COLS>(g.pn), planes * G), dim3(WS::THREADS), WS::LDS_BYTES,
+                           st, T, slab, tw, g, nb, G, gstride);
+        return hipGetLastError();
+    } else {
+        return hipErrorNotSupported;
+    }
+}
+
+template <int LOG2N>
+hipError_t launch_ypass_wave(const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb, int planes,
+                             int G, int gstride, hipStream_t st)
+{
+    if (g.tcl == 2) return launch_ypass_wave_tc<LOG2N, 4>(T, slab, tw, g, nb, planes, G, gstride, st);
+    if (g.tcl == 3) return launch_ypass_wave_tc<LOG2N, 8>(T, slab, tw, g, nb, planes, G, gstride, st);
+    return hipErrorNotSupported;
+}
+
+#define LITHO_DEFINE_WAVE_OPS(L2)                                                                            \
+    template hipError_t launch_ypass_wave<L2>(const float2*, float*, const float2*, const PassGeom&, int, int, int, \
+                                              int, hipStream_t);
+
+}  // namespace litho

@@ -12,6 +12,8 @@ FFTFLAGS := -fno-signed-zeros -fno-slp-vectorize
 # scheduling strategy.  Same-box A/B (us per source point, default vs max-ilp): N = 4096 (k_ypass_wave) 9.21 -> 9.03,
 # N = 2048 1.82 -> 1.80, N = 8192 (k_ypass_pair, barriers) 46.6 -> 51.4: max-ilp for N = 4096 only.
 WAVEFLAGS_12 ?= -mllvm -amdgpu-sched-strategy=max-ilp
+# and the N = 8192 split x-pass: 28.5 -> 27.0 us per source point at 4096^2 (the N = 4096 x-pass prefers the default)
+INSTFLAGS_13 ?= -mllvm -amdgpu-sched-strategy=max-ilp
 INST := $(patsubst $(CSRC)/%.hip,build/%.o,$(wildcard $(CSRC)/inst_*.hip))
 INSTW := $(patsubst $(CSRC)/%.hip,build/%.o,$(wildcard $(CSRC)/instw_*.hip))
 HDRS := $(CSRC)/fft_core.hpp $(CSRC)/wave_fft.hpp $(CSRC)/engine_kernels.hpp $(CSRC)/wave_kernels.hpp $(CSRC)/engine_common.hpp include/litho_abbe.h
@@ -20,7 +22,7 @@ all: $(OUT) oracle
 
 build/inst_%.o: $(CSRC)/inst_%.hip $(HDRS)
 	@mkdir -p build
-	$(HIPCC) $(HIPFLAGS) $(FFTFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) $(FFTFLAGS) $(INSTFLAGS_$*) -c $< -o $@
 build/instw_%.o: $(CSRC)/instw_%.hip $(HDRS)
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) $(FFTFLAGS) $(WAVEFLAGS_$*) -c $< -o $@

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void k_ypass_rect(
     static_assert(LOG2N >= 9 && LOG2N <= 11, "multi-column-per-wave y-pass: N = 512, 1024, 2048");
     static_assert(TC == 4 || TC == 8, "T tiles are 4 or 8 columns wide");
     using W = WaveSq<6>;
-    constexpr int S = 64, N = 1 << LOG2N, NL = (S * S) / N, H = S / NL, JL = H / 4;
+    constexpr int S = 64, N = 1 << LOG2N, NL = (S * S) / N, H = S / NL, JL = H / 8;   // live rows: |k| <= pn/4 = N/8 = 64 JL
     static_assert(NL <= TC, "the wave's columns must sit in one T tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);

@@ -51,6 +51,29 @@ __global__ void k_rows_multi(float* __restrict__ T, int rows, int cols, int reps
         }
     }
 }
+// Whole 128-byte lines from ONE 16-byte store instruction whose two 64-byte halves come from lanes c and c + 32
+// (rows a, a + 1 of an 8-column tile held by the two half-waves): does the coalescer merge across the half-waves?
+// SPLIT = 0: lanes c..c+7 cover a line (reference).  One wave = 8 lines per instruction, T as [tile8][row][8].
+template <int SPLIT>
+__global__ void k_lines(float* __restrict__ T, int rows, int cols, int reps)
+{
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int pairs = (rows + 1) / 2;
+    if (wave >= pairs) return;
+    const int a0 = 2 * wave;
+    int r, m;                                        // row inside the pair, 16-byte column slot 0..31 of this store
+    if (SPLIT) { r = lane >> 5; m = lane & 31; }
+    else { r = (lane >> 2) & 1; m = (lane >> 3) * 4 + (lane & 3); }
+    const f4 v = {1.f, 2.f, (float)r, (float)m};
+    for (int rep = 0; rep < reps; ++rep) {
+        float* base = T + (size_t)rep * rows * cols * 2;
+        for (int k = 0; k < cols / 64; ++k) {        // 64 columns (32 slots of 2) per store instruction
+            const int q = 64 * k + 2 * m;
+            const size_t off = (((size_t)(q / 8) * rows + a0 + r) * 8 + (q % 8)) * 2;
+            if (a0 + r < rows) *reinterpret_cast<f4*>(base + off) = v;
+        }
+    }
+}
 __global__ void k_contig(float* __restrict__ T, size_t n4)
 {
     const f4 v = {1.f, 2.f, 3.f, 4.f};
@@ -84,5 +107,9 @@ int main()
     printf("B2 32-B granules, 2 rows per WG back to back : %.3f ms = %.2f TB/s\n", ms, bytes / ms / 1e9);
     ms = time_ms([&] { k_rows_multi<4><<<(rows + 3) / 4, 256>>>(T, rows, cols, reps); });
     printf("B4 32-B granules, 4 rows per WG back to back : %.3f ms = %.2f TB/s\n", ms, bytes / ms / 1e9);
+    ms = time_ms([&] { k_lines<0><<<((rows + 1) / 2 + 3) / 4, 256>>>(T, rows, cols, reps); });
+    printf("L0 full lines, 8 consecutive lanes per line (2 rows x 64 B)   : %.3f ms = %.2f TB/s\n", ms, bytes / ms / 1e9);
+    ms = time_ms([&] { k_lines<1><<<((rows + 1) / 2 + 3) / 4, 256>>>(T, rows, cols, reps); });
+    printf("L1 full lines, halves from lanes c and c+32                   : %.3f ms = %.2f TB/s\n", ms, bytes / ms / 1e9);
     return 0;
 }

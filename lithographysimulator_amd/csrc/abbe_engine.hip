@@ -214,7 +214,7 @@ static int env_int(const char* name, int dflt)
 
 // Tuning / test knobs.  Read ONCE per C-ABI call (the parity tests flip them between calls), never per launch.
 struct Knobs {
-    int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk, xsplit, rect;
+    int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk, xsplit, rect, xrect;
     static Knobs read()
     {
         Knobs k;
@@ -230,6 +230,7 @@ struct Knobs {
         k.plane_chunk = env_int("LITHO_ABBE_PLANE_CHUNK", 0);
         k.xsplit = env_int("LITHO_ABBE_XSPLIT", 1);
         k.rect = env_int("LITHO_ABBE_RECT", 1);
+        k.xrect = env_int("LITHO_ABBE_XRECT", 1);
         return k;
     }
 };
@@ -410,7 +411,13 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     if (G < 1) G = 1;
     // N = 8192 = 2 pn: each row as two 4096-point transforms (k_xpass_split) instead of the 8192-point engine
     const bool split_x = !general && variant == 1 && N == 8192 && g.tcl >= 2 && kn.xsplit;
-    const bool fused_x = !split_x && !general && variant >= 0 && !(use_w64 && N == 4096 && kn.w64x && g.tcl == 2);
+    // Several box rows per wave on the wave-level engine, whole-line T stores (k_xpass_rect).  Measured (us per source
+    // point, radix-16 x-pass -> k_xpass_rect): N = 1024 0.57 -> 0.36, N = 2048 1.43 -> 1.46, N = 512 0.27 -> 0.26: its
+    // loads are not prefetched (no registers left), so it only pays where the radix-16 engine is at its weakest.
+    // LITHO_ABBE_XRECT: 0 off, 1 N = 1024 only (default), 2 every N <= 2048 (parity tests).
+    const bool rect_x = !general && variant == 1 && pn * 2 == N && N >= 512 && N <= 2048 && g.tcl == 3 &&
+                        (kn.xrect >= 2 || (kn.xrect == 1 && N == 1024));
+    const bool fused_x = !split_x && !rect_x && !general && variant >= 0 && !(use_w64 && N == 4096 && kn.w64x && g.tcl == 2);
 
     // Batch = source points per launch pair.  The intermediate T of one batch (PC planes x points) should stay
     // resident in the 256 MiB Infinity Cache between the two passes (measured at 2048^2: 63 items = 1 GiB ->
@@ -453,7 +460,11 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
             const int nb = (int)((S - s0 < bs) ? (S - s0) : bs);
             const int* sh = shifts + 2 * s0;
             if (fresh) { marks.add(-1, 0); fresh = false; }
-            if (split_x) {
+            if (rect_x) {
+                for (int q = 0; q < pc; ++q)
+                    HIP_TRY(ops->xpass_rect(Pc + (size_t)q * pn * pn, M, sh, w.T + (size_t)q * nb * g.t_point, w.twtab, g, nb,
+                                            xchunk, st));
+            } else if (split_x) {
                 for (int q = 0; q < pc; ++q)
                     HIP_TRY(ops->xpass_split(Pc + (size_t)q * pn * pn, M, sh, w.T + (size_t)q * nb * g.t_point, w.twtab, g,
                                              nb, xchunk, st));
@@ -506,7 +517,7 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     }
     g_last_plan[0] = general; g_last_plan[1] = r0; g_last_plan[2] = c0; g_last_plan[3] = h;
     g_last_plan[4] = wdt; g_last_plan[5] = bs; g_last_plan[6] = nx; g_last_plan[7] = variant;
-    g_last_plan[8] = PC; g_last_plan[9] = G; g_last_plan[10] = xchunk; g_last_plan[11] = fused_x ? 1 : (split_x ? 2 : 0);
+    g_last_plan[8] = PC; g_last_plan[9] = G; g_last_plan[10] = xchunk; g_last_plan[11] = fused_x ? 1 : (split_x ? 2 : (rect_x ? 3 : 0));
     return LITHO_OK;
 }
 

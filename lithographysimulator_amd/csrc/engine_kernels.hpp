@@ -646,6 +646,9 @@ struct SizeOps {
     // N = 2 pn as two N/2-point transforms per row (k_xpass_split; N = 8192 only): hipErrorNotSupported otherwise
     hipError_t (*xpass_split)(const float2* P, const float2* M, const int* shifts, float2* T, const float2* tw,
                               const PassGeom& g, int nb, int chunk, hipStream_t st);
+    // several adjacent box rows per wave, whole-line T stores (k_xpass_rect; N = 512..2048, 8-column tiles)
+    hipError_t (*xpass_rect)(const float2* P, const float2* M, const int* shifts, float2* T, const float2* tw,
+                             const PassGeom& g, int nb, int chunk, hipStream_t st);
     hipError_t (*xpass_real_fwd)(const RealImageLoader& ld, float2* T, const float2* tw, const PassGeom& g,
                                  hipStream_t st);
     // y-pass over `planes` planes x G groups per plane (grid.y = planes * G); slab of (plane, group) =
@@ -684,6 +687,10 @@ static hipError_t set_lds(LdsOnce& once, K kern, size_t bytes)
 template <int LOG2N>
 hipError_t launch_ypass_wave(const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb, int planes,
                              int G, int gstride, hipStream_t st);
+
+template <int LOG2N>
+hipError_t launch_xpass_rect(const float2* P, const float2* M, const int* shifts, float2* T, const float2* tw,
+                             const PassGeom& g, int nb, int chunk, hipStream_t st);
 
 template <int LOG2N>
 struct SizeImpl {
@@ -751,6 +758,12 @@ struct SizeImpl {
         } else {
             return hipErrorNotSupported;
         }
+    }
+    static hipError_t xpass_rect(const float2* P, const float2* M, const int* shifts, float2* T, const float2* tw,
+                                 const PassGeom& g, int nb, int chunk, hipStream_t st)
+    {
+        if constexpr (LOG2N >= 9 && LOG2N <= 13) return launch_xpass_rect<LOG2N>(P, M, shifts, T, tw, g, nb, chunk, st);
+        else return hipErrorNotSupported;
     }
     static hipError_t xpass_real_fwd(const RealImageLoader& ld, float2* T, const float2* tw, const PassGeom& g,
                                      hipStream_t st)
@@ -837,7 +850,8 @@ struct SizeImpl {
     const SizeOps* size_ops_##L2()                                                                   \
     {                                                                                                \
         static const SizeOps ops{&SizeImpl<L2>::xpass_abbe, &SizeImpl<L2>::xpass_general,            \
-                                 &SizeImpl<L2>::xpass_split, &SizeImpl<L2>::xpass_real_fwd, &SizeImpl<L2>::ypass_acc,            \
+                                 &SizeImpl<L2>::xpass_split, &SizeImpl<L2>::xpass_rect,              \
+                                 &SizeImpl<L2>::xpass_real_fwd, &SizeImpl<L2>::ypass_acc,            \
                                  &SizeImpl<L2>::ypass_field, &SizeImpl<L2>::xpass_w64,               \
                                  &SizeImpl<L2>::ypass_w64};                                          \
         return &ops;                                                                                 \

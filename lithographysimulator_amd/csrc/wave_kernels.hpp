@@ -288,6 +288,103 @@ __global__ __launch_bounds__(256, 2) void k_ypass_rect(
 }
 
 
+// ----------------------------------------------------------------------------------
+// x-pass on the wave-level engine for N = 512, 1024, 2048 with pn = N/2, pupil inside the unit disk, no wrapping
+// shift, 8-column T tiles: NL = 8, 4, 2 ADJACENT ROWS of the pupil box per wave (WaveSq<6>::run_rect).  Work item of
+// a wave = (group of NL rows, source point); it walks a chunk of source points for its row group.  Per item: the
+// live pupil and mask-spectrum samples of the NL rows are loaded through windowed descriptors (validity = hardware
+// range check) and multiplied, run_rect transforms the NL rows at once, and every store instruction then holds NL
+// rows x 64/NL consecutive columns: rows 2i, 2i+1 of an 8-column tile are adjacent 64-byte runs, so each
+// instruction writes WHOLE 128-byte lines (measured 4.2-4.3 TB/s against 3.4 for the 64-byte granules of the
+// one-row-per-workgroup x-pass, scripts/ubench/write_bw.hip L0/L1).  No workgroup barriers.
+// ----------------------------------------------------------------------------------
+template <int LOG2N>
+__global__ __launch_bounds__(256, 2) void k_xpass_rect(
+    const float2* __restrict__ P, const float2* __restrict__ M, const int* __restrict__ shifts,
+    float2* __restrict__ Tbuf, const float2* __restrict__ twtab, PassGeom g, int nb, int chunk)
+{
+    static_assert(LOG2N >= 9 && LOG2N <= 11, "multi-row-per-wave x-pass: N = 512, 1024, 2048");
+    using W = WaveSq<6>;
+    constexpr int S = 64, N = 1 << LOG2N, NL = (S * S) / N, H = S / NL, JL = H / 8, TC = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* lds = smem + wv * W::LDS_FLOATS;
+    typename W::LaneTwiddles tw;
+    W::load_lane_twiddles(tw, twtab, lane, 1);
+
+    const int a0 = (blockIdx.x * 4 + wv) * NL;                  // first box row of this wave's group (multiple of NL)
+    const int s_begin = blockIdx.y * chunk;
+    const int s_end = min(nb, s_begin + chunk);
+    if (a0 >= g.rows) return;                                   // whole wave idle (no barriers in this kernel)
+
+    // input: slot (line, j) <-> row a0 + line, sample n = lane + 64 j: k = n for j <= JL, k = n - N for j >= H - JL.
+    // Descriptors are windowed on the valid columns [kx0, kx1) of each row (a left-of-window slot wraps to a huge
+    // unsigned offset), so every slot address is one register + a compile-time constant.
+    const unsigned win_bytes = (unsigned)(g.kx1 - g.kx0) * 8u;
+    const unsigned vb = (unsigned)(lane - g.kx0) * 8u;
+    auto slot_off = [&](int j) { return vb + (unsigned)(j <= JL ? 512 * j : 512 * j - 8 * N); };
+    const int r0 = g.ky0 + g.c + a0;                            // row of P (and, shifted, of M) for line 0
+
+    // output: lane c = (line = c / H, m = c % H) holds X_line[m + H k2]; column q = u + c with u = m + H k2 (k2 < 16)
+    // or m + H k2 - N (k2 >= 48).  H k2 + c is a multiple of 8, so tile = (m >> 3) + (H k2 + c) / 8, column in tile = m & 7.
+    const int oline = lane / H, om = lane & (H - 1);
+    const bool ovalid = a0 + oline < g.rows;
+    const unsigned rowstride = (unsigned)g.rows * (TC * 8u);    // bytes between consecutive tiles
+    const unsigned obase = ovalid ? (unsigned)(om >> 3) * rowstride + (unsigned)(a0 + oline) * (TC * 8u) + (unsigned)(om & 7) * 8u
+                                  : BUF_OOB;
+
+    for (int s = s_begin; s < s_end; ++s) {
+        const int dy = shifts[2 * s], dx = shifts[2 * s + 1];
+        float2 x[S];
+        static_for<0, NL>([&](auto q_) {
+            constexpr int line = decltype(q_)::value;
+            const bool rvalid = a0 + line < g.rows;
+            const __amdgpu_buffer_rsrc_t rP =
+                make_rsrc(P + (size_t)(r0 + (rvalid ? line : 0)) * g.pn + g.c + g.kx0, rvalid ? win_bytes : 0u);
+            const __amdgpu_buffer_rsrc_t rM =
+                make_rsrc(M + (size_t)(r0 + (rvalid ? line : 0) + dy) * g.pn + dx + g.c + g.kx0, rvalid ? win_bytes : 0u);
+            static_for<0, H>([&](auto j_) {
+                constexpr int j = decltype(j_)::value;
+                if constexpr (j <= JL || j >= H - JL) x[line * H + j] = cmul(buf_load_c64(rP, slot_off(j)), buf_load_c64(rM, slot_off(j)));
+                else x[line * H + j] = make_float2(0.f, 0.f);
+            });
+        });
+        W::template run_rect<NL>(x, tw, lds, lane);
+        const __amdgpu_buffer_rsrc_t rT =
+            make_rsrc(Tbuf + (size_t)s * g.t_point, (size_t)g.t_point * sizeof(float2));
+        static_for<0, S / 2>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            constexpr int k2 = i < S / 4 ? i : S / 2 + i;
+            constexpr int ub = k2 < S / 2 ? H * k2 : H * k2 - N;            // u - m
+            const unsigned tile_off = (unsigned)((ub + g.c) >> 3) * rowstride;
+            buf_store_c64(rT, obase == BUF_OOB ? BUF_OOB : obase + tile_off, x[W::brev(k2)]);
+        });
+    }
+}
+
+template <int LOG2N>
+hipError_t launch_xpass_rect(const float2* P, const float2* M, const int* shifts, float2* T, const float2* tw,
+                             const PassGeom& g, int nb, int chunk, hipStream_t st)
+{
+    if constexpr (LOG2N >= 9 && LOG2N <= 11) {
+        if (g.tcl != 3) return hipErrorNotSupported;
+        static LdsOnce once;
+        constexpr size_t lds = 4 * WaveSq<6>::LDS_FLOATS * sizeof(float);
+        constexpr int NL = 4096 >> LOG2N;
+        auto kern = k_xpass_rect<LOG2N>;
+        hipError_t e = set_lds(once, kern, lds);
+        if (e != hipSuccess) return e;
+        const int groups = (g.rows + NL - 1) / NL;
+        hipLaunchKernelGGL(kern, dim3((groups + 3) / 4, (nb + chunk - 1) / chunk), dim3(256), lds, st, P, M, shifts, T, tw,
+                           g, nb, chunk);
+        return hipGetLastError();
+    } else {
+        return hipErrorNotSupported;
+    }
+}
+
 template <int LOG2N, int TC>
 static hipError_t launch_ypass_wave_tc(const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb, int planes, int G,
                      int gstride, hipStream_t st)
@@ -352,6 +449,8 @@ hipError_t launch_ypass_wave(const float2* T, float* slab, const float2* tw, con
 
 #define LITHO_DEFINE_WAVE_OPS(L2)                                                                            \
     template hipError_t launch_ypass_wave<L2>(const float2*, float*, const float2*, const PassGeom&, int, int, int, \
-                                              int, hipStream_t);
+                                              int, hipStream_t);                                             \
+    template hipError_t launch_xpass_rect<L2>(const float2*, const float2*, const int*, float2*, const float2*,  \
+                                              const PassGeom&, int, int, hipStream_t);
 
 }  // namespace litho

@@ -293,8 +293,12 @@ def test_stack_plane_chunk_knob_and_generic_variant(L, dev, monkeypatch):
     sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateAnnular(), pn)
     sel = sh[(torch.arange(37, device=dev) * sh.shape[0]) // 37]
     ref = L.abbeIntensity(mft, stack, sel, N).cpu()
-    assert nat.last_plan()["fused_xpass"] == 1
-    for env in ({"LITHO_ABBE_PLANE_CHUNK": "1"}, {"LITHO_ABBE_PLANE_CHUNK": "2"}, {"LITHO_ABBE_PLANE_CHUNK": "3"},
+    assert nat.last_plan()["fused_xpass"] == 3                      # N = 1024: k_xpass_rect, plane by plane
+    fused = _with_env(monkeypatch, L, {"LITHO_ABBE_XRECT": "0"}, lambda: L.abbeIntensity(mft, stack, sel, N).cpu())
+    assert nat.last_plan()["fused_xpass"] == 1                      # the plane-fused radix-16 x-pass
+    for k in range(6):
+        assert rel_max(fused[k], ref[k]) < 2e-6, k
+    for env in ({"LITHO_ABBE_PLANE_CHUNK": "1"}, {"LITHO_ABBE_XRECT": "0", "LITHO_ABBE_PLANE_CHUNK": "4"}, {"LITHO_ABBE_PLANE_CHUNK": "2"}, {"LITHO_ABBE_PLANE_CHUNK": "3"},
                 {"LITHO_ABBE_PLANE_CHUNK": "6"}, {"LITHO_ABBE_FORCE_GENERIC": "1"}, {"LITHO_ABBE_FORCE_GENERAL": "1"},
                 {"LITHO_ABBE_W64": "0"}, {"LITHO_ABBE_BATCH": "5", "LITHO_ABBE_XCHUNK": "2"}):
         got = _with_env(monkeypatch, L, env, lambda: L.abbeIntensity(mft, stack, sel, N).cpu())
@@ -474,7 +478,13 @@ def test_2048_kernels_agree_1024(L, dev, monkeypatch):
     sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateAnnular(), pn)
     sel = sh[(torch.arange(75, device=dev) * sh.shape[0]) // 75]
     ref = L.abbeIntensity(mft, pf, sel, N).cpu()
+    from lithographysimulator_amd import _native as nat
+    assert nat.last_plan()["fused_xpass"] == 1
+    forced = _with_env(monkeypatch, L, {"LITHO_ABBE_XRECT": "2"}, lambda: L.abbeIntensity(mft, pf, sel, N).cpu())
+    assert nat.last_plan()["fused_xpass"] == 3                      # k_xpass_rect: two box rows per wave (opt-in here)
+    assert rel_max(forced, ref) < 2e-6
     for env in ({"LITHO_ABBE_RECT": "0"}, {"LITHO_ABBE_W64": "0"}, {"LITHO_ABBE_TILE": "4"},
+                {"LITHO_ABBE_XRECT": "2", "LITHO_ABBE_RECT": "0"}, {"LITHO_ABBE_XRECT": "2", "LITHO_ABBE_XCHUNK": "3"},
                 {"LITHO_ABBE_TILE": "4", "LITHO_ABBE_RECT": "0"}, {"LITHO_ABBE_GROUPS": "3", "LITHO_ABBE_BATCH": "10"}):
         got = _with_env(monkeypatch, L, env, lambda: L.abbeIntensity(mft, pf, sel, N).cpu())
         assert rel_max(got, ref) < 2e-6, env
@@ -505,7 +515,9 @@ def test_small_size_kernels_agree(L, dev, monkeypatch, pn):
         assert nat.last_profile()["ypass_kernel"] == "k_ypass_wave"          # the wave-level family (k_ypass_rect here)
     finally:
         nat.set_profiling(False)
-    for env in ({"LITHO_ABBE_RECT": "0"}, {"LITHO_ABBE_W64": "0"}, {"LITHO_ABBE_TILE": "4"}, {"LITHO_ABBE_GROUPS": "5"}):
+    assert nat.last_plan()["fused_xpass"] == (3 if pn == 512 else 1)    # k_xpass_rect (4 box rows per wave) at N = 1024
+    for env in ({"LITHO_ABBE_RECT": "0"}, {"LITHO_ABBE_W64": "0"}, {"LITHO_ABBE_TILE": "4"}, {"LITHO_ABBE_GROUPS": "5"},
+                {"LITHO_ABBE_XRECT": "0"}, {"LITHO_ABBE_XRECT": "2"}, {"LITHO_ABBE_XRECT": "2", "LITHO_ABBE_XCHUNK": "7"}):
         got = _with_env(monkeypatch, L, env, lambda: L.abbeIntensity(mft, pf, sel, N).cpu())
         assert rel_max(got, ref) < 2e-6, env
     o = O()

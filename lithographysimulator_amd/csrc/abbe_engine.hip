@@ -328,49 +328,33 @@ struct MarkList {
     }
 };
 
-static int abbe_accumulate(const float2* M, const float2* P, int planes, const int* shifts, int64_t S,
-                           const int* count_dev, int64_t* count_out, int pn, int N, float* out, void* ws,
-                           size_t ws_bytes, hipStream_t st)
+// Everything abbe_accumulate decides before its launch loop: which kernels run and how the work is batched.
+struct AbbePlan {
+    PassGeom g;
+    int general, variant;       // 1: roll kept on P (wrapping shifts); kernel specialisation (-1 generic, else log2(N/pn))
+    int r0, c0, h, wdt;         // pupil support box (rows r0 .. r0+h, columns c0 .. c0+wdt)
+    bool wave_y;                // y-pass by the wave-level family (k_ypass_wave / k_ypass_pair / k_ypass_rect)
+    bool split_x, rect_x, fused_x;   // x-pass: k_xpass_split / k_xpass_rect / plane-fused k_xpass_abbe (else per-plane fall-backs)
+    int PC, G, xchunk;          // planes in flight per launch pair, y-pass groups per plane, source points per x-pass workgroup
+    int64_t bs;                 // source points per batch
+};
+
+// pl = the 9 plan words read back from the device (pupil box, shift extents, count)
+static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const int pl[9], int pn, int N, int planes)
 {
-    int rc = check_sizes(pn, N);
-    if (rc) return rc;
-    if (!M || !P || !out || planes < 1 || S < 0 || (S > 0 && !shifts)) return LITHO_E_ARG;
-    if (count_out) *count_out = 0;
-    if (S == 0) return LITHO_OK;
-    Workspace w;
-    if (!carve(ws, ws_bytes, pn, N, w)) return LITHO_E_WORKSPACE;
-    const Knobs kn = Knobs::read();
-
-    hipLaunchKernelGGL(k_twiddle_table, dim3((N + 255) / 256), dim3(256), 0, st, w.twtab, N);
-    hipLaunchKernelGGL(k_plan_init, dim3(1), dim3(64), 0, st, w.plan);
-    hipLaunchKernelGGL(k_pupil_box, dim3((pn + BOX_ROWS_PER_BLOCK - 1) / BOX_ROWS_PER_BLOCK, planes), dim3(256), 0, st,
-                       P, pn, w.plan);
-    hipLaunchKernelGGL(k_shift_extents, dim3(256), dim3(256), 0, st, shifts, (long long)S, count_dev, w.plan);
-    HIP_TRY(hipGetLastError());
-    int pl[9];
-    rc = read_plan(w, pl, st);                               // the ONE host wait of the image path
-    if (rc) return rc;
-    S = pl[8];                                               // = S, or the device-side count of the source list
-    if (count_out) *count_out = S;
-    if (S == 0 || pl[1] < pl[0]) return LITHO_OK;            // no source point / pupil identically zero: nothing to add
-
     int r0 = pl[0], h = pl[1] - pl[0] + 1, c0 = pl[2], wdt = pl[3] - pl[2] + 1;
     const bool nowrap = (r0 + pl[4] >= 0) && (r0 + h - 1 + pl[5] <= pn - 1) &&
                         (c0 + pl[6] >= 0) && (c0 + wdt - 1 + pl[7] <= pn - 1);
-    int general = (!nowrap || kn.force_general) ? 1 : 0;
+    const int general = (!nowrap || kn.force_general) ? 1 : 0;
     if (general) { r0 = 0; c0 = 0; h = pn; wdt = pn; }
-    PassGeom g;
+    PassGeom& g = pp.g;
     make_geom(g, pn, N, r0, c0, h, wdt, general, kn.tile > 0 ? kn.tile : 4);
-    const SizeOps* ops = size_ops(ilog2(N));
-    if (!ops) return LITHO_E_ARG;
     const int variant = pick_variant(g, kn);
 
-    // y-pass groups: the grid is (tile blocks) x (planes in flight) x G workgroups; pick the smallest group
-    // count that makes it a whole number of full-occupancy rounds (256 CUs x workgroups per CU).
-    const int l2n = ilog2(N);
-    const int lines_per_wg = (N / 16 >= 64) ? 1 : 64 / (N / 16);
     // wave-level y-pass kernels, N = 2 pn: N = 512, 1024, 2048 k_ypass_rect (8, 4, 2 columns per wave; fall-back
     // k_ypass_wave with S = 32 for 1024 and 2048), N = 4096 k_ypass_wave (S = 64), N = 8192 k_ypass_pair
+    const int l2n = ilog2(N);
+    const int lines_per_wg = (N / 16 >= 64) ? 1 : 64 / (N / 16);
     const bool rect_ok = kn.rect && (N == 2048 || N == 1024 || (N == 512 && (kn.tile <= 0 || kn.tile == 8)));
     const bool w64_ok = (pn * 2 == N) && ((N == 512 && rect_ok) || N == 1024 || N == 2048 || N == 4096 ||
                                           (N == 8192 && kn.w64_8192));   // w64_8192 defaults to 1
@@ -384,13 +368,16 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     // k_ypass_rect: 4096 / N adjacent columns per wave (they must fit one T tile)
     const bool rect = rect_ok && N <= 2048 && (4096 / N) <= tc;
     g.rect_off = rect ? 0 : 1;
-    const bool use_w64 = variant == 1 && w64_shape && (g.tcl == 2 || g.tcl == 3) && (N != 512 || rect);
+    const bool wave_y = variant == 1 && w64_shape && (g.tcl == 2 || g.tcl == 3) && (N != 512 || rect);
+
+    // y-pass groups: the grid is (column blocks) x (planes in flight) x G workgroups; pick the smallest group
+    // count that makes it a whole number of full-occupancy rounds (256 CUs x workgroups per CU).
     const int wave_cols = rect ? 4 * (4096 / N) : N == 1024 ? 8 : (N == 8192 ? 2 : 4);   // columns per wave-kernel workgroup
     const int wave_wpt = tc > wave_cols ? tc / wave_cols : 1;         // workgroups that share one T tile
-    const int tile_blocks = !use_w64 ? (g.nt + lines_per_wg - 1) / lines_per_wg
+    const int tile_blocks = !wave_y ? (g.nt + lines_per_wg - 1) / lines_per_wg
                             : wave_wpt == 1 ? (pn + wave_cols - 1) / wave_cols
                                             : wave_wpt * (((pn + tc - 1) / tc + 7) / 8 * 8);
-    const int resident = 256 * (use_w64 ? ((N <= 2048 && !rect) ? 4 : 2) : l2n <= 12 ? 3 : (l2n == 13 ? 2 : 1));
+    const int resident = 256 * (wave_y ? ((N <= 2048 && !rect) ? 4 : 2) : l2n <= 12 ? 3 : (l2n == 13 ? 2 : 1));
     int a_ = tile_blocks, b_ = resident;
     while (b_) { const int t_ = a_ % b_; a_ = b_; b_ = t_; }
     int Gtot = resident / a_;                                  // groups that fill whole rounds
@@ -407,30 +394,21 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     int PC = planes < 2 ? planes : 2;
     if (kn.plane_chunk > 0) PC = kn.plane_chunk < planes ? kn.plane_chunk : planes;
     if (PC > g_cap(pn)) PC = g_cap(pn);
-    int G = Gtot / PC;                                         // groups per plane
-    if (G < 1) G = 1;
-    // N = 8192 = 2 pn: each row as two 4096-point transforms (k_xpass_split) instead of the 8192-point engine
-    const bool split_x = !general && variant == 1 && N == 8192 && g.tcl >= 2 && kn.xsplit;
-    // Several box rows per wave on the wave-level engine, whole-line T stores (k_xpass_rect).  Measured (us per source
-    // point, radix-16 x-pass -> k_xpass_rect): N = 1024 0.57 -> 0.36, N = 2048 1.43 -> 1.46, N = 512 0.27 -> 0.26: its
-    // loads are not prefetched (no registers left), so it only pays where the radix-16 engine is at its weakest.
-    // LITHO_ABBE_XRECT: 0 off, 1 N = 1024 only (default), 2 every N <= 2048 (parity tests).
-    const bool rect_x = !general && variant == 1 && pn * 2 == N && N >= 512 && N <= 2048 && g.tcl == 3 &&
-                        (kn.xrect >= 2 || (kn.xrect == 1 && N == 1024));
-    const bool fused_x = !split_x && !rect_x && !general && variant >= 0 && !(use_w64 && N == 4096 && kn.w64x && g.tcl == 2);
 
     // Batch = source points per launch pair.  The intermediate T of one batch (PC planes x points) should stay
-    // resident in the 256 MiB Infinity Cache between the two passes (measured at 2048^2: 63 items = 1 GiB ->
+    // around the size of the 256 MiB Infinity Cache between the two passes (measured at 2048^2: 63 items = 1 GiB ->
     // 28.7 us/item, 16 items = 270 MB -> 21.9), and a y-pass workgroup wants several points per plane to amortise
     // its accumulator flush.
     const size_t item_bytes = (size_t)g.t_point * sizeof(float2);
     const int64_t items_ws = (int64_t)(w.t_bytes / item_bytes);
+    if (items_ws < 1) return LITHO_E_WORKSPACE;
     int64_t items = items_ws;
     int64_t items_cache = (int64_t)(((size_t)288 << 20) / item_bytes);
     if (items_cache < 8) items_cache = 8;
     if (items > items_cache) items = items_cache;
-    if (items_ws < 1) return LITHO_E_WORKSPACE;
     if (PC > items_ws) PC = (int)items_ws;
+    int G = Gtot / PC;                                         // groups per plane
+    if (G < 1) G = 1;
     int64_t bs = items / PC;
     if (kn.batch > 0) bs = kn.batch;
     if (bs > items_ws / PC) bs = items_ws / PC;
@@ -446,58 +424,102 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
         if (want == 4) for (int cand : {4, 5, 3, 6, 2}) if (bs % cand == 0) { xchunk = cand; break; }
         if (want == 2) for (int cand : {2, 3, 1}) if (bs % cand == 0) { xchunk = cand; break; }
     }
-    const size_t slab_plane = (size_t)g.nt * 4 * pn;
+
+    // N = 8192 = 2 pn: each row as two 4096-point transforms (k_xpass_split) instead of the 8192-point engine
+    pp.split_x = !general && variant == 1 && N == 8192 && g.tcl >= 2 && kn.xsplit;
+    // Several box rows per wave on the wave-level engine, whole-line T stores (k_xpass_rect).  Measured (us per source
+    // point, radix-16 x-pass -> k_xpass_rect): N = 1024 0.57 -> 0.36, N = 2048 1.43 -> 1.46, N = 512 0.27 -> 0.26: its
+    // loads are not prefetched (no registers left), so it only pays where the radix-16 engine is at its weakest.
+    // LITHO_ABBE_XRECT: 0 off, 1 N = 1024 only (default), 2 every N <= 2048 (parity tests).
+    pp.rect_x = !general && variant == 1 && pn * 2 == N && N >= 512 && N <= 2048 && g.tcl == 3 &&
+                (kn.xrect >= 2 || (kn.xrect == 1 && N == 1024));
+    const bool wave_x_optin = wave_y && N == 4096 && kn.w64x && g.tcl == 2;      // k_xpass_w64 (slower, parity-tested)
+    pp.fused_x = !pp.split_x && !pp.rect_x && !general && variant >= 0 && !wave_x_optin;
+    pp.general = general; pp.variant = variant; pp.r0 = r0; pp.c0 = c0; pp.h = h; pp.wdt = wdt;
+    pp.wave_y = wave_y; pp.PC = PC; pp.G = G; pp.xchunk = xchunk; pp.bs = bs;
+    return LITHO_OK;
+}
+
+static int abbe_accumulate(const float2* M, const float2* P, int planes, const int* shifts, int64_t S,
+                           const int* count_dev, int64_t* count_out, int pn, int N, float* out, void* ws,
+                           size_t ws_bytes, hipStream_t st)
+{
+    int rc = check_sizes(pn, N);
+    if (rc) return rc;
+    if (!M || !P || !out || planes < 1 || S < 0 || (S > 0 && !shifts)) return LITHO_E_ARG;
+    if (count_out) *count_out = 0;
+    if (S == 0) return LITHO_OK;
+    Workspace w;
+    if (!carve(ws, ws_bytes, pn, N, w)) return LITHO_E_WORKSPACE;
+    const SizeOps* ops = size_ops(ilog2(N));
+    if (!ops) return LITHO_E_ARG;
+    const Knobs kn = Knobs::read();
+
+    hipLaunchKernelGGL(k_twiddle_table, dim3((N + 255) / 256), dim3(256), 0, st, w.twtab, N);
+    hipLaunchKernelGGL(k_plan_init, dim3(1), dim3(64), 0, st, w.plan);
+    hipLaunchKernelGGL(k_pupil_box, dim3((pn + BOX_ROWS_PER_BLOCK - 1) / BOX_ROWS_PER_BLOCK, planes), dim3(256), 0, st,
+                       P, pn, w.plan);
+    hipLaunchKernelGGL(k_shift_extents, dim3(256), dim3(256), 0, st, shifts, (long long)S, count_dev, w.plan);
+    HIP_TRY(hipGetLastError());
+    int pl[9];
+    rc = read_plan(w, pl, st);                               // the ONE host wait of the image path
+    if (rc) return rc;
+    S = pl[8];                                               // = S, or the device-side count of the source list
+    if (count_out) *count_out = S;
+    if (S == 0 || pl[1] < pl[0]) return LITHO_OK;            // no source point / pupil identically zero: nothing to add
+
+    AbbePlan pp;
+    rc = plan_abbe(pp, w, kn, pl, pn, N, planes);
+    if (rc) return rc;
+    const PassGeom& g = pp.g;
+    const int variant = pp.variant, G = pp.G, xchunk = pp.xchunk;
+    const int64_t bs = pp.bs;
+    const size_t slab_plane = (size_t)g.nt * 4 * pn, plane_elems = (size_t)pn * pn;
     int64_t nx = 0;
     // profiling: ONE event per kernel-class boundary (E0 x E1 y E2 x E3 ...); consecutive events bracket the
     // launches of one pass over one batch.  (Two events recorded back to back alias on ROCm, so no begin/end pairs.)
     MarkList marks(g_profiling != 0, st);
-    for (int p0 = 0; p0 < planes; p0 += PC) {
-        const int pc = (planes - p0 < PC) ? planes - p0 : PC;
-        const float2* Pc = P + (size_t)p0 * pn * pn;
+    for (int p0 = 0; p0 < planes; p0 += pp.PC) {
+        const int pc = (planes - p0 < pp.PC) ? planes - p0 : pp.PC;
+        const float2* Pc = P + (size_t)p0 * plane_elems;
         HIP_TRY(hipMemsetAsync(w.slab, 0, (size_t)pc * G * slab_plane * sizeof(float), st));
         bool fresh = true;                                     // start a new timing interval after memset / reduce
         for (int64_t s0 = 0; s0 < S; s0 += bs) {
             const int nb = (int)((S - s0 < bs) ? (S - s0) : bs);
             const int* sh = shifts + 2 * s0;
             if (fresh) { marks.add(-1, 0); fresh = false; }
-            if (rect_x) {
-                for (int q = 0; q < pc; ++q)
-                    HIP_TRY(ops->xpass_rect(Pc + (size_t)q * pn * pn, M, sh, w.T + (size_t)q * nb * g.t_point, w.twtab, g, nb,
-                                            xchunk, st));
-            } else if (split_x) {
-                for (int q = 0; q < pc; ++q)
-                    HIP_TRY(ops->xpass_split(Pc + (size_t)q * pn * pn, M, sh, w.T + (size_t)q * nb * g.t_point, w.twtab, g,
-                                             nb, xchunk, st));
-            } else if (fused_x) {
-                for (int q = 0; q < pc;) {
-                    const int np = variant == 0 ? 1 : (pc - q >= 4) ? 4 : (pc - q >= 2 ? 2 : 1);
-                    HIP_TRY(ops->xpass_abbe(variant, np, Pc + (size_t)q * pn * pn, M, sh,
-                                            w.T + (size_t)q * nb * g.t_point, w.twtab, g, nb, xchunk, st));
-                    q += np;
+            // ---- x-pass: T item (plane q of the chunk, point s) = q * nb + s
+            for (int q = 0; q < pc;) {
+                const float2* Pq = Pc + (size_t)q * plane_elems;
+                float2* Tq = w.T + (size_t)q * nb * g.t_point;
+                int np = 1;
+                if (pp.rect_x) {
+                    HIP_TRY(ops->xpass_rect(Pq, M, sh, Tq, w.twtab, g, nb, xchunk, st));
+                } else if (pp.split_x) {
+                    HIP_TRY(ops->xpass_split(Pq, M, sh, Tq, w.twtab, g, nb, xchunk, st));
+                } else if (pp.fused_x) {
+                    np = variant == 0 ? 1 : (pc - q >= 4) ? 4 : (pc - q >= 2 ? 2 : 1);
+                    HIP_TRY(ops->xpass_abbe(variant, np, Pq, M, sh, Tq, w.twtab, g, nb, xchunk, st));
+                } else if (pp.general) {
+                    AbbeLoader ld{Pq, M, sh, nullptr, nullptr, 0, 0};
+                    HIP_TRY(ops->xpass_general(ld, Tq, w.twtab, g, nb, st));
+                } else if (variant >= 0) {
+                    HIP_TRY(ops->xpass_w64(Pq, M, sh, Tq, w.twtab, g, nb, st));
+                } else {
+                    HIP_TRY(ops->xpass_abbe(-1, 1, Pq, M, sh, Tq, w.twtab, g, nb, xchunk, st));
                 }
-            } else {
-                for (int q = 0; q < pc; ++q) {
-                    const float2* Pq = Pc + (size_t)q * pn * pn;
-                    float2* Tq = w.T + (size_t)q * nb * g.t_point;
-                    if (general) {
-                        AbbeLoader ld{Pq, M, sh, nullptr, nullptr, 0, 0};
-                        HIP_TRY(ops->xpass_general(ld, Tq, w.twtab, g, nb, st));
-                    } else if (variant >= 0) {
-                        HIP_TRY(ops->xpass_w64(Pq, M, sh, Tq, w.twtab, g, nb, st));
-                    } else {
-                        HIP_TRY(ops->xpass_abbe(-1, 1, Pq, M, sh, Tq, w.twtab, g, nb, xchunk, st));
-                    }
-                }
+                q += np;
             }
             marks.add(0, nb * pc);
+            // ---- y-pass: every plane of the chunk, G groups each (fewer when the batch is shorter than G)
             const int Geff = nb < G ? nb : G;
-            if (use_w64) HIP_TRY(ops->ypass_w64(w.T, w.slab, w.twtab, g, nb, pc, Geff, G, st));
+            if (pp.wave_y) HIP_TRY(ops->ypass_w64(w.T, w.slab, w.twtab, g, nb, pc, Geff, G, st));
             else HIP_TRY(ops->ypass_acc(variant, w.T, w.slab, w.twtab, g, nb, pc, Geff, G, st));
             marks.add(1, nb * pc);
             ++nx;
         }
         hipLaunchKernelGGL(k_slab_reduce, dim3((pn + 31) / 32, (pn + 31) / 32, pc), dim3(256), 0, st,
-                           w.slab, out + (size_t)p0 * pn * pn, pn, g.nt * 4, G, G);
+                           w.slab, out + (size_t)p0 * plane_elems, pn, g.nt * 4, G, G);
         HIP_TRY(hipGetLastError());
     }
     if (g_profiling) {
@@ -512,12 +534,13 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
                 g_profile[m.kind * 3 + 2] += m.items;
             }
         }
-        g_profile[6] = use_w64 ? 1 : 0;
-        g_profile[7] = PC;
+        g_profile[6] = pp.wave_y ? 1 : 0;
+        g_profile[7] = pp.PC;
     }
-    g_last_plan[0] = general; g_last_plan[1] = r0; g_last_plan[2] = c0; g_last_plan[3] = h;
-    g_last_plan[4] = wdt; g_last_plan[5] = bs; g_last_plan[6] = nx; g_last_plan[7] = variant;
-    g_last_plan[8] = PC; g_last_plan[9] = G; g_last_plan[10] = xchunk; g_last_plan[11] = fused_x ? 1 : (split_x ? 2 : (rect_x ? 3 : 0));
+    g_last_plan[0] = pp.general; g_last_plan[1] = pp.r0; g_last_plan[2] = pp.c0; g_last_plan[3] = pp.h;
+    g_last_plan[4] = pp.wdt; g_last_plan[5] = bs; g_last_plan[6] = nx; g_last_plan[7] = variant;
+    g_last_plan[8] = pp.PC; g_last_plan[9] = G; g_last_plan[10] = xchunk;
+    g_last_plan[11] = pp.fused_x ? 1 : (pp.split_x ? 2 : (pp.rect_x ? 3 : 0));
     return LITHO_OK;
 }
 

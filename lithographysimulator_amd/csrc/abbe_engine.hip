@@ -160,6 +160,7 @@ static int g_cap(int pn)
     return n < 8 ? 8 : (n > 64 ? 64 : (int)n);
 }
 static constexpr size_t T_BUDGET_MAX = (size_t)1 << 30;
+static constexpr size_t T_BUDGET_MIN = (size_t)256 << 20;
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -168,6 +169,7 @@ static size_t t_budget(int pn)
     const size_t nt = (pn + 3) / 4;
     const size_t one_general = nt * (size_t)pn * 4 * sizeof(float2);
     size_t b = 64 * one_general;
+    if (b < T_BUDGET_MIN) b = T_BUDGET_MIN;                  // small images: room for batches of several points per y-pass group
     if (b > T_BUDGET_MAX) b = T_BUDGET_MAX;
     if (b < one_general + one_general / 2) b = one_general + one_general / 2;
     return b;

@@ -116,12 +116,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
-    dev = torch.device("cuda", local_rank)
+    # Test hooks (tests/test_gpu_bench_contract.py): on a box with ONE GPU the multi-rank code path of this file is
+    # exercised with every rank on cuda:0 and a gloo group (RCCL refuses two ranks on one device).
+    backend = os.environ.get("LITHO_BENCH_BACKEND", "nccl")
+    share_gpu = os.environ.get("LITHO_BENCH_SHARE_GPU") == "1"
+    dev = torch.device("cuda", 0 if share_gpu else local_rank)
     torch.cuda.set_device(dev)
     group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)          # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
         group = dist.group.WORLD
 
     import lithographysimulator_amd as L
@@ -184,7 +191,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3

@@ -127,6 +127,33 @@ def test_other_fft_ratios_vs_golden(golden, L, dev, ps):
     assert rel_max(img, ref) < TOL_IMAGE_MAX
 
 
+@pytest.mark.parametrize("pn,ps", [(512, 48), (512, 10), (1024, 48), (256, 10)])
+def test_other_fft_ratios_mid_size_vs_oracle(L, dev, pn, ps):
+    """N = pn (pixelSize 48: the RL = 0 pruned kernels, 9 live input slots) and N = 4 pn (pixelSize 10: RL = 2) at
+    sizes where a line spans whole workgroups, against the CPU oracle's op chain and its post-process."""
+    from lithographysimulator_amd import _native as nat
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    o = O()
+    mask = L.Mask(bernoulli_mask(pn), ps, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, ps, WL)
+    assert N == (pn if ps == 48 else 4 * pn)
+    pf = L.Pupil(pn, WL, NA, f16(DEMO_AB), dev).generatePupilFunction()
+    sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateQuasar(4, -math.pi / 8), pn)
+    sel = sh[(torch.arange(12, device=dev) * sh.shape[0]) // 12]
+    raw = L.abbeIntensity(mft, pf, sel, N).cpu()
+    assert nat.last_plan()["variant"] == (0 if ps == 48 else 2) and nat.last_plan()["general"] == 0
+    ref = o.abbe_raw(mft.cpu(), pf.cpu(), sel.cpu(), N)
+    assert rel_max(raw, ref) < TOL_IMAGE_MAX and rel_l2(raw, ref) < TOL_IMAGE_L2
+    img = L.postProcess(raw.to(dev), eps).cpu()
+    ref_img = o.post_process(ref, eps)
+    assert img.shape == ref_img.shape and rel_max(img, ref_img) < TOL_IMAGE_MAX
+    stack = L.throughFocusPupils(pn, WL, NA, f16(DEMO_AB), [-60.0, 40.0, 120.0], dev)     # planes through NP = 1 / 2 launches
+    both = L.abbeIntensity(mft, stack, sel[:5], N).cpu()
+    for k in range(3):
+        assert rel_max(both[k], L.abbeIntensity(mft, stack[k], sel[:5], N).cpu()) < 1e-6
+
+
 def test_non_power_of_two_mask(golden, L, dev):
     from lithographysimulator_amd.synthetic import bernoulli_mask
     g = golden("g5_images.npz")

@@ -228,6 +228,32 @@ def test_subsampled_baseline_sizes_vs_golden(golden, L, dev, pn, K, skind, ab):
     assert abs(float(img.double().sum()) / float(g[f"sub{pn}_final_sum"]) - 1) < 2e-5
 
 
+@pytest.mark.parametrize("pn,K,skind,ab", [(1024, 6, "annular", [0, 0, 0, 0, 100]), (2048, 3, "quasar", DEMO_AB),
+                                           (4096, 1, "annular", [0, 0, 0, 0, 100])])
+def test_whole_image_vs_oracle_at_baseline_sizes(L, dev, pn, K, skind, ab):
+    """The golden fixtures at 1024^2 .. 4096^2 hold a centre crop and the row / column sums (size limits).  Here EVERY
+    pixel of the raw intensity and of the post-processed image is compared with the CPU oracle's op chain (itself
+    pinned against those goldens in the CPU suite) for a few source points spread over the real list."""
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    o = O()
+    torch.set_num_threads(min(32, torch.get_num_threads() if torch.get_num_threads() > 1 else 32))
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    ls = L.LightSource(0.4, 0.8, pn, NA, device=dev)
+    sh = L.sourceShifts(ls.generateAnnular() if skind == "annular" else ls.generateQuasar(4, -math.pi / 8), pn)
+    sel = sh[((2 * torch.arange(K, device=dev) + 1) * sh.shape[0]) // (2 * K)]
+    pf = L.Pupil(pn, WL, NA, f16(ab), dev).generatePupilFunction()
+    raw = L.abbeIntensity(mft, pf, sel, N)
+    ref = o.abbe_raw(mft.cpu(), pf.cpu(), sel.cpu(), N)
+    e_max, e_l2 = rel_max(raw.cpu(), ref), rel_l2(raw.cpu(), ref)
+    print(f"{pn}^2 whole image, {K} points: rel-to-max {e_max:.2e}, rel-L2 {e_l2:.2e}")
+    assert e_max < TOL_IMAGE_MAX and e_l2 < TOL_IMAGE_L2
+    img = L.postProcess(raw, eps).cpu()
+    ref_img = o.post_process(ref, eps)
+    assert img.shape == ref_img.shape and rel_max(img, ref_img) < TOL_IMAGE_MAX
+
+
 # ------------------------------------------------------------------ through-focus stack (G6)
 def test_through_focus_stack(golden, L, dev):
     from lithographysimulator_amd.synthetic import bernoulli_mask

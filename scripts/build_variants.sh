@@ -9,7 +9,7 @@ cd "$(dirname "$0")/.."
 L2=$1; shift
 mkdir -p build/variants
 BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC"
-OBJS="build/abbe_engine.o build/optics.o $(ls build/inst_*.o | grep -v inst_$L2)"
+OBJS="build/abbe_engine.o build/optics.o $(ls build/inst_*.o | grep -v inst_$L2) $(ls build/instw_*.o)"
 hipcc $BASE -DLITHO_DIAG_BUILD -c lithographysimulator_amd/csrc/common.hip -o build/variants/common_diag.o
 build() {
   local extra="" common="build/common.o"

@@ -400,7 +400,8 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
     // Batch = source points per launch pair.  The intermediate T of one batch (PC planes x points) should stay
     // INSIDE the 256 MiB Infinity Cache between the two passes, and a y-pass workgroup wants several points per plane
     // to amortise its accumulator flush.  Measured (us per source point, round 2): 1024^2 (4.2 MB per item) 32 items
-    // 3.01, 48 2.85, 56 2.84, 68 3.09; 2048^2 (16.8 MB) 8 items 14.65, 10 14.16, 12 13.63, 17 13.98 -> budget 208 MiB.
+    // 3.01, 48 2.85, 56 2.84, 68 3.09; 2048^2 (16.8 MB) 8 items 14.65, 12 and 17 equal within the +-2.5 % scatter of
+    // single samples (profiles/r02_tuning_sweeps.txt) -> budget 208 MiB.
     const size_t item_bytes = (size_t)g.t_point * sizeof(float2);
     const int64_t items_ws = (int64_t)(w.t_bytes / item_bytes);
     if (items_ws < 1) return LITHO_E_WORKSPACE;

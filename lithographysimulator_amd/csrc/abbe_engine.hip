@@ -389,10 +389,10 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
 
     // Through-focus stacks: PC planes are in flight per launch pair.  The fused x-pass gathers the mask-spectrum
     // window of a source point once for all of them (NP = 4 / 2 / 1 planes per workgroup); the y-pass gives every
-    // plane its own groups and slabs.  The cache-resident T budget (~17 items at 2048^2) is shared by the planes in
-    // flight, so more planes mean fewer source points per y-pass accumulator flush.  Measured at 2048^2 x 8 planes
-    // (us per source point and plane): PC = 1 14.2, PC = 2 14.3, PC = 4 15.9 -- the gather was never the x-pass's
-    // limit (its T stores are), so PC = 2: half the gathers at equal speed.  LITHO_ABBE_PLANE_CHUNK overrides.
+    // plane its own groups and slabs.  The T buffer of a launch pair holds PC x batch items for the planes in
+    // flight.  The gather was never the x-pass's limit (its T stores are): PC = 2 takes 40 % of the x-pass's load
+    // instructions away at equal x-pass time, but its 2 x batch items of T leave the Infinity Cache and the y-pass
+    // pays 4-5 % for that (2-3 % of the total against plane-by-plane).  LITHO_ABBE_PLANE_CHUNK overrides.
     int PC = planes < 2 ? planes : 2;
     if (kn.plane_chunk > 0) PC = kn.plane_chunk < planes ? kn.plane_chunk : planes;
     if (PC > g_cap(pn)) PC = g_cap(pn);
@@ -412,7 +412,11 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
     if (PC > items_ws) PC = (int)items_ws;
     int G = Gtot / PC;                                         // groups per plane
     if (G < 1) G = 1;
-    int64_t bs = items / PC;
+    // Stacks keep the per-plane batch: T grows to PC x batch items and leaves the Infinity Cache, which costs the
+    // y-pass less than flushing its accumulators twice as often (alternating A/B at 2048^2 x 8 planes, us per point
+    // and plane, two boxes: PC = 1 13.40 / 13.76; PC = 2 with the batch halved 14.18, with the full batch 13.62 /
+    // 14.05; PC = 4 13.68).
+    int64_t bs = items;
     if (kn.batch > 0) bs = kn.batch;
     if (bs > items_ws / PC) bs = items_ws / PC;
     if (bs < 1) bs = 1;
@@ -422,7 +426,9 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
     if (kn.batch <= 0 && bs > G) bs -= bs % G;
     int xchunk = kn.xchunk;                                    // source points per x-pass workgroup
     if (xchunk <= 0) {
-        const int want = PC >= 4 ? 1 : (PC >= 2 ? 2 : 4);      // ~4 transforms per workgroup
+        // ~4 source points per workgroup: the pupil rows (5 loads per plane) are amortised over the chunk, the
+        // mask-spectrum window of each point over the planes (measured flat between 3 and 6 points)
+        const int want = PC >= 4 ? 2 : 4;
         xchunk = want;
         if (want == 4) for (int cand : {4, 5, 3, 6, 2}) if (bs % cand == 0) { xchunk = cand; break; }
         if (want == 2) for (int cand : {2, 3, 1}) if (bs % cand == 0) { xchunk = cand; break; }

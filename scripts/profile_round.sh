@@ -11,7 +11,7 @@ python3 bench.py --workload cfg1 > $O/bench_cfg1.json 2>/dev/null
 python3 bench.py --workload cfg2 > $O/bench_cfg2.json 2>/dev/null
 python3 bench.py --workload cfg4 --shard 0/8 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_cfg4_shard0of8.json 2>/dev/null
 python3 bench.py --workload cfg5 --steps 1 --warmup 0 --no-cpu-baseline > $O/bench_cfg5.json 2>/dev/null
-bash scripts/pmc_traffic.sh $R cfg3 510 cfg2 2040 cfg4 64 cfg5 128
+bash scripts/pmc_traffic.sh $R cfg3 504 cfg2 2016 cfg4 64 cfg5 120 cfg1 3233
 # keep the summaries small: the raw per-dispatch CSVs stay in gpurun_out
 find $O -name "*_agent_info.csv" -delete
 ls -la $O

@@ -360,17 +360,19 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
     const bool rect_ok = kn.rect && (N == 2048 || N == 1024 || (N == 512 && (kn.tile <= 0 || kn.tile == 8)));
     const bool w64_ok = (pn * 2 == N) && ((N == 512 && rect_ok) || N == 1024 || N == 2048 || N == 4096 ||
                                           (N == 8192 && kn.w64_8192));   // w64_8192 defaults to 1
-    const bool w64_shape = w64_ok && kn.w64;
+    // N = pn (the coarse-grid transform, and pixel sizes that give N = pn): full-output variants of the same kernels
+    const bool full_ok = (pn == N) && (N == 1024 || N == 2048 || N == 4096);
+    const bool w64_shape = ((w64_ok && variant == 1) || (full_ok && variant == 0)) && kn.w64;
     // T tile width.  The x-pass's T stores are bound by the memory system's rate for partial-line writes: measured
     // (scripts/ubench/write_bw.hip) 2.2 TB/s for 32-byte granules (4-column tiles), 3.4 TB/s for 64-byte granules
     // (8 columns), 5.2 TB/s for whole 128-byte lines.  The wave kernels read 8-column tiles at no extra cost, the
     // radix-16 y-pass does not (measured in round 1), so: 8 columns on the wave path, 4 elsewhere.
-    if (kn.tile <= 0 && variant == 1 && w64_shape && !kn.w64x) set_tile(g, h, 8);
+    if (kn.tile <= 0 && w64_shape && !kn.w64x) set_tile(g, h, 8);
     const int tc = 1 << g.tcl;
     // k_ypass_rect: 4096 / N adjacent columns per wave (they must fit one T tile)
-    const bool rect = rect_ok && N <= 2048 && (4096 / N) <= tc;
+    const bool rect = (variant == 0 ? N <= 2048 : rect_ok && N <= 2048) && (4096 / N) <= tc;
     g.rect_off = rect ? 0 : 1;
-    const bool wave_y = variant == 1 && w64_shape && (g.tcl == 2 || g.tcl == 3) && (N != 512 || rect);
+    const bool wave_y = w64_shape && (g.tcl == 2 || g.tcl == 3) && (N != 512 || rect) && (variant == 1 || rect || N == 4096);
 
     // y-pass groups: the grid is (column blocks) x (planes in flight) x G workgroups; pick the smallest group
     // count that makes it a whole number of full-occupancy rounds (256 CUs x workgroups per CU).
@@ -442,7 +444,7 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
     // LITHO_ABBE_XRECT: 0 off, 1 N = 1024 only (default), 2 every N <= 2048 (parity tests).
     pp.rect_x = !general && variant == 1 && pn * 2 == N && N >= 512 && N <= 2048 && g.tcl == 3 &&
                 (kn.xrect >= 2 || (kn.xrect == 1 && N == 1024));
-    const bool wave_x_optin = wave_y && N == 4096 && kn.w64x && g.tcl == 2;      // k_xpass_w64 (slower, parity-tested)
+    const bool wave_x_optin = wave_y && variant == 1 && N == 4096 && kn.w64x && g.tcl == 2;      // k_xpass_w64 (slower, parity-tested)
     pp.fused_x = !pp.split_x && !pp.rect_x && !general && variant >= 0 && !wave_x_optin;
     pp.general = general; pp.variant = variant; pp.r0 = r0; pp.c0 = c0; pp.h = h; pp.wdt = wdt;
     pp.wave_y = wave_y; pp.PC = PC; pp.G = G; pp.xchunk = xchunk; pp.bs = bs;

@@ -56,7 +56,9 @@ static inline int wave_grid_x(int pn)
     else return WPT * (((pn + TC - 1) / TC + 7) / 8 * 8);
 }
 
-template <int LOG2N, int TC>
+// FULL = false: N = 2 pn (half of the bins are kept, a quarter of the inputs live).  FULL = true: N = pn -- the
+// "coarse grid" transform (every bin kept, half of the inputs live; D = 1 only), see k_ypass_rect.
+template <int LOG2N, int TC, bool FULL = false>
 __global__ __launch_bounds__(WaveShape<LOG2N>::THREADS, WaveShape<LOG2N>::MINWAVES) void k_ypass_wave(
     const float2* __restrict__ Tbuf, float* __restrict__ slab, const float2* __restrict__ twtab,
     PassGeom g, int nb, int G, int gstride)
@@ -64,7 +66,10 @@ __global__ __launch_bounds__(WaveShape<LOG2N>::THREADS, WaveShape<LOG2N>::MINWAV
     static_assert(TC == 4 || TC == 8, "T tiles are 4 or 8 columns wide");
     using WS = WaveShape<LOG2N>;
     using W = typename WS::W;
-    constexpr int S = WS::S, D = WS::D, JLIVE = WS::JLIVE, N = 1 << LOG2N;
+    static_assert(!FULL || WS::D == 1, "full-output variant: one unit per column");
+    constexpr int S = WS::S, D = WS::D, JLIVE = FULL ? 2 * WS::JLIVE : WS::JLIVE, N = 1 << LOG2N;
+    constexpr int NACC = FULL ? S : S / 2;                   // kept bins per lane
+    auto kept_k2 = [](int i) constexpr { return FULL ? i : (i < S / 4 ? i : S / 2 + i); };
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -86,8 +91,8 @@ __global__ __launch_bounds__(WaveShape<LOG2N>::THREADS, WaveShape<LOG2N>::MINWAV
     Tbuf += (size_t)plane * nb * g.t_point;
     slab += (size_t)plane * gstride * g.nt * 4 * g.pn;
     const bool active = tile * TC < g.pn;
-    float acc[S / 2];
-    static_for<0, S / 2>([&](auto i) { acc[i] = 0.f; });
+    float acc[NACC];
+    static_for<0, NACC>([&](auto i) { acc[i] = 0.f; });
 
     // Live input slots j (sub-transform sample n' = l + S j): k = n' for j <= JLIVE, k = n' - S*S for the upper
     // ones (sample n' + N - S*S of the full line); T row a = k - ky0.  The descriptor is windowed on this tile's
@@ -122,9 +127,9 @@ __global__ __launch_bounds__(WaveShape<LOG2N>::THREADS, WaveShape<LOG2N>::MINWAV
         });
         W::run(x, tw, lds, lane);
         // kept bins of the sub-transform: v in [-S*S/4, S*S/4)  ->  k2 in [0, S/4) and [3S/4, S)
-        static_for<0, S / 2>([&](auto i_) {
+        static_for<0, NACC>([&](auto i_) {
             constexpr int i = decltype(i_)::value;
-            constexpr int k2 = i < S / 4 ? i : S / 2 + i;
+            constexpr int k2 = kept_k2(i);
             const float2 v = x[W::brev(k2)];
             acc[i] = fmaf(v.x, v.x, fmaf(v.y, v.y, acc[i]));
         });
@@ -132,9 +137,9 @@ __global__ __launch_bounds__(WaveShape<LOG2N>::THREADS, WaveShape<LOG2N>::MINWAV
 
     if (!active || qx >= g.pn) return;
     float* srow = slab + ((size_t)grp * g.nt * 4 + qx) * g.pn;
-    static_for<0, S / 2>([&](auto i_) {
+    static_for<0, NACC>([&](auto i_) {
         constexpr int i = decltype(i_)::value;
-        constexpr int k2 = i < S / 4 ? i : S / 2 + i;
+        constexpr int k2 = kept_k2(i);
         const int n = l + S * k2;
         const int v = n < S * S / 2 ? n : n - S * S;        // bin of the sub-transform
         srow[D * v + p + g.c] += acc[i];                    // bin u = D v + p of the full line
@@ -216,7 +221,11 @@ __global__ __launch_bounds__(256, 2) void k_ypass_pair(
 // 8 NL contiguous bytes of a T tile: NL/2 16-byte loads.  Workgroup = 4 waves = 4 NL columns.
 // ----------------------------------------------------------------------------------
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-template <int LOG2N, int TC>
+// FULL = false: N = 2 pn.  FULL = true: N = pn, the COARSE-GRID transform -- the Abbe sum is accumulated on the
+// pn x pn grid q = 2 v that spans the whole period (E_s(2v) = sum_k A_s[k] w_pn^(k v)): every bin is kept
+// (64 accumulators per lane) and |k| <= pn/4 = N/4 of the inputs are live; abbe_engine.hip reconstructs the fine
+// image from it (band-limited interpolation + the exact Nyquist-line correction).
+template <int LOG2N, int TC, bool FULL = false>
 __global__ __launch_bounds__(256, 2) void k_ypass_rect(
     const float2* __restrict__ Tbuf, float* __restrict__ slab, const float2* __restrict__ twtab,
     PassGeom g, int nb, int G, int gstride)
@@ -224,7 +233,10 @@ __global__ __launch_bounds__(256, 2) void k_ypass_rect(
     static_assert(LOG2N >= 9 && LOG2N <= 11, "multi-column-per-wave y-pass: N = 512, 1024, 2048");
     static_assert(TC == 4 || TC == 8, "T tiles are 4 or 8 columns wide");
     using W = WaveSq<6>;
-    constexpr int S = 64, N = 1 << LOG2N, NL = (S * S) / N, H = S / NL, JL = H / 8;   // live rows: |k| <= pn/4 = N/8 = 64 JL
+    constexpr int S = 64, N = 1 << LOG2N, NL = (S * S) / N, H = S / NL;
+    constexpr int JL = FULL ? H / 4 : H / 8;                 // live rows: |k| <= pn/4 = 64 JL
+    constexpr int NACC = FULL ? S : S / 2;                   // kept bins per lane
+    auto kept_k2 = [](int i) constexpr { return FULL ? i : (i < S / 4 ? i : S / 2 + i); };
     static_assert(NL <= TC, "the wave's columns must sit in one T tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);
@@ -240,8 +252,8 @@ __global__ __launch_bounds__(256, 2) void k_ypass_rect(
     Tbuf += (size_t)plane * nb * g.t_point;
     slab += (size_t)plane * gstride * g.nt * 4 * g.pn;
     const bool active = tile * TC < g.pn;
-    float acc[S / 2];
-    static_for<0, S / 2>([&](auto i) { acc[i] = 0.f; });
+    float acc[NACC];
+    static_for<0, NACC>([&](auto i) { acc[i] = 0.f; });
 
     // slot j (of every line) <-> sample n = lane + 64 j: k = n for j <= JL, k = n - N for j >= H - JL; T row a = k - ky0
     constexpr int RB = 8 * TC;
@@ -268,9 +280,9 @@ __global__ __launch_bounds__(256, 2) void k_ypass_rect(
             });
         });
         W::template run_rect<NL>(x, tw, lds, lane);
-        static_for<0, S / 2>([&](auto i_) {
+        static_for<0, NACC>([&](auto i_) {
             constexpr int i = decltype(i_)::value;
-            constexpr int k2 = i < S / 4 ? i : S / 2 + i;
+            constexpr int k2 = kept_k2(i);
             const float2 v = x[W::brev(k2)];
             acc[i] = fmaf(v.x, v.x, fmaf(v.y, v.y, acc[i]));
         });
@@ -279,9 +291,9 @@ __global__ __launch_bounds__(256, 2) void k_ypass_rect(
     const int qx = qx0 + lane / H, m = lane & (H - 1);
     if (!active || qx >= g.pn) return;
     float* srow = slab + ((size_t)grp * g.nt * 4 + qx) * g.pn;
-    static_for<0, S / 2>([&](auto i_) {
+    static_for<0, NACC>([&](auto i_) {
         constexpr int i = decltype(i_)::value;
-        constexpr int k2 = i < S / 4 ? i : S / 2 + i;
+        constexpr int k2 = kept_k2(i);
         constexpr int ubase = k2 < S / 2 ? H * k2 : H * k2 - N;             // bin u = m + H k2 (mod N, centred)
         srow[ubase + m + g.c] += acc[i];
     });
@@ -389,13 +401,36 @@ template <int LOG2N, int TC>
 static hipError_t launch_ypass_wave_tc(const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb, int planes, int G,
                      int gstride, hipStream_t st)
 {
+    constexpr size_t lds4 = 4 * WaveSq<6>::LDS_FLOATS * sizeof(float);       // four waves, one 64 x 65 matrix each
+    if (g.N == g.pn) {                                  // coarse-grid transforms (N = pn): every bin kept
+        if constexpr (LOG2N == 12) {
+            static LdsOnce once;
+            auto kern = k_ypass_wave<LOG2N, TC, true>;
+            hipError_t e = set_lds(once, kern, lds4);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, 4>(g.pn), planes * G), dim3(256), lds4, st, T, slab, tw, g, nb, G,
+                               gstride);
+            return hipGetLastError();
+        } else if constexpr (LOG2N == 10 || LOG2N == 11) {
+            constexpr int NL = 4096 >> LOG2N;
+            if constexpr (NL <= TC) {
+                static LdsOnce once;
+                auto kern = k_ypass_rect<LOG2N, TC, true>;
+                hipError_t e = set_lds(once, kern, lds4);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, 4 * NL>(g.pn), planes * G), dim3(256), lds4, st, T, slab, tw,
+                                   g, nb, G, gstride);
+                return hipGetLastError();
+            }
+        }
+        return hipErrorNotSupported;
+    }
     if constexpr (LOG2N == 13) {
         static LdsOnce once;
-        constexpr size_t lds = 4 * WaveSq<6>::LDS_FLOATS * sizeof(float);
         auto kern = k_ypass_pair<LOG2N, TC>;
-        hipError_t e = set_lds(once, kern, lds);
+        hipError_t e = set_lds(once, kern, lds4);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, 2>(g.pn), planes * G), dim3(256), lds, st, T, slab, tw, g, nb, G,
+        hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, 2>(g.pn), planes * G), dim3(256), lds4, st, T, slab, tw, g, nb, G,
                            gstride);
         return hipGetLastError();
     } else if constexpr (LOG2N >= 9 && LOG2N <= 11) {
@@ -403,11 +438,10 @@ static hipError_t launch_ypass_wave_tc(const float2* T, float* slab, const float
         if constexpr (NL <= TC) {
             if (!g.rect_off) {
                 static LdsOnce once;
-                constexpr size_t lds = 4 * WaveSq<6>::LDS_FLOATS * sizeof(float);
                 auto kern = k_ypass_rect<LOG2N, TC>;
-                hipError_t e = set_lds(once, kern, lds);
+                hipError_t e = set_lds(once, kern, lds4);
                 if (e != hipSuccess) return e;
-                hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, 4 * NL>(g.pn), planes * G), dim3(256), lds, st, T, slab, tw,
+                hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, 4 * NL>(g.pn), planes * G), dim3(256), lds4, st, T, slab, tw,
                                    g, nb, G, gstride);
                 return hipGetLastError();
             }
@@ -424,7 +458,7 @@ static hipError_t launch_ypass_wave_tc(const float2* T, float* slab, const float
         } else {
             return hipErrorNotSupported;
         }
-    } else if constexpr (LOG2N >= 10 && LOG2N <= 12) {
+    } else if constexpr (LOG2N == 12) {
         static LdsOnce once;
         using WS = WaveShape<LOG2N>;
         auto kern = k_ypass_wave<LOG2N, TC>;

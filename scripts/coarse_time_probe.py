@@ -1,0 +1,23 @@
+import math, os, sys, torch
+sys.path.insert(0, "/root/repo")
+import lithographysimulator_amd as L
+from lithographysimulator_amd import _native as nat
+from lithographysimulator_amd.synthetic import bernoulli_mask
+pn = int(sys.argv[1]); K = int(sys.argv[2])
+dev = torch.device("cuda", 0)
+mask = L.Mask(bernoulli_mask(pn), 25, dev); mft = mask.fraunhofer(193., True)
+ab = torch.tensor([0, 0, 0.01, 0, 100, 0.01, 0, 0.01, 0.01, 0.01], dtype=torch.float16)
+pf = L.Pupil(pn, 193., 0.7, ab, dev).generatePupilFunction()
+sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, 0.7, device=dev).generateQuasar(4, -math.pi / 8), pn)
+sel = sh[sh.shape[0] // 3: sh.shape[0] // 3 + K].contiguous()
+for N in (2 * pn, pn):
+    L.abbeIntensity(mft, pf, sel, N)
+    nat.set_profiling(True)
+    best = None
+    for _ in range(3):
+        L.abbeIntensity(mft, pf, sel, N); torch.cuda.synchronize()
+        p = nat.last_profile()
+        cur = (p["xpass_ms"] / p["xpass_points"] * 1e3, p["ypass_ms"] / p["ypass_points"] * 1e3)
+        best = cur if best is None or sum(cur) < sum(best) else best
+    nat.set_profiling(False)
+    print(f"pn={pn} N={N}: x-pass {best[0]:.2f} y-pass {best[1]:.2f} sum {sum(best):.2f} us/pt  plan {nat.last_plan()}")

@@ -127,7 +127,7 @@ def test_other_fft_ratios_vs_golden(golden, L, dev, ps):
     assert rel_max(img, ref) < TOL_IMAGE_MAX
 
 
-@pytest.mark.parametrize("pn,ps", [(512, 48), (512, 10), (1024, 48), (256, 10)])
+@pytest.mark.parametrize("pn,ps", [(512, 48), (512, 10), (1024, 48), (256, 10), (2048, 48)])
 def test_other_fft_ratios_mid_size_vs_oracle(L, dev, pn, ps):
     """N = pn (pixelSize 48: the RL = 0 pruned kernels, 9 live input slots) and N = 4 pn (pixelSize 10: RL = 2) at
     sizes where a line spans whole workgroups, against the CPU oracle's op chain and its post-process."""
@@ -140,7 +140,7 @@ def test_other_fft_ratios_mid_size_vs_oracle(L, dev, pn, ps):
     assert N == (pn if ps == 48 else 4 * pn)
     pf = L.Pupil(pn, WL, NA, f16(DEMO_AB), dev).generatePupilFunction()
     sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateQuasar(4, -math.pi / 8), pn)
-    sel = sh[(torch.arange(12, device=dev) * sh.shape[0]) // 12]
+    sel = sh[(torch.arange(12 if pn < 2048 else 4, device=dev) * sh.shape[0]) // (12 if pn < 2048 else 4)]
     raw = L.abbeIntensity(mft, pf, sel, N).cpu()
     assert nat.last_plan()["variant"] == (0 if ps == 48 else 2) and nat.last_plan()["general"] == 0
     ref = o.abbe_raw(mft.cpu(), pf.cpu(), sel.cpu(), N)

@@ -205,8 +205,9 @@ def main():
     prof = nat.last_profile()
     plan = nat.last_plan()
     nat.set_profiling(False)
-    lines = {"xpass": plan["box_rows"], "ypass": pn}            # length-N lines transformed per T item
-    line_flops = 5.0 * N * math.log2(N)                          # nominal FFT flops of one length-N line
+    lines = {"xpass": plan["box_rows"], "ypass": pn}            # lines transformed per T item
+    n_exec = pn if plan.get("coarse_grid") else N                # coarse-grid path: pn-point transforms on the grid q = 2 v
+    line_flops = 5.0 * n_exec * math.log2(n_exec)                # nominal FFT flops of one transformed line
     kern = {}
     for k in ("xpass", "ypass"):
         launches = max(1, prof[f"{k}_launches"])
@@ -265,7 +266,7 @@ def main():
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic",
            "config": {"workload": f"BASELINE {args.workload}: {desc}" + (f" [{shard_note}]" if shard_note else ""),
-                      "pn": pn, "fft_n": N, "source_points": S, "source_points_full": S_full, "planes": planes,
+                      "pn": pn, "fft_n": N, "executed_fft_n": n_exec, "source_points": S, "source_points_full": S_full, "planes": planes,
                       "points_per_rank": math.ceil(S / world), "pixel_size": PS, "wavelength": WL, "NA": NA,
                       "parallelism": f"source-point shards x{world}, one all-reduce" if world > 1 else "single GPU",
                       "plan": plan, "image_shape": list(image.shape)},

@@ -122,9 +122,10 @@ int litho_mask_spectrum(const int16_t *geometry, int pn, double epsilon, int N, 
  * [2]=box col0, [3]=box rows, [4]=box cols, [5]=points per batch, [6]=x-pass launches,
  * [7]=kernel variant (-1 generic, else log2(N/pn) of the pruned specialisation), [8]=planes in flight per
  * launch pair (through-focus stacks), [9]=y-pass groups per plane, [10]=source points per x-pass workgroup,
- * [11]=1 when the plane-fused x-pass ran (mask-spectrum window gathered once per source point for all planes
- * in flight). */
-int litho_abbe_last_plan(int64_t fields_host[12]);
+ * [11]=x-pass kernel family (1 plane-fused k_xpass_abbe, 2 k_xpass_split, 3 k_xpass_rect, 0 fall-backs),
+ * [12]=1 when the coarse-grid path ran (pn-point transforms on the grid q = 2 v, fine image reconstructed once
+ * per plane), [13..15] reserved. */
+int litho_abbe_last_plan(int64_t fields_host[16]);
 
 /* ---- Per-kernel timing for bench.py: when on, litho_abbe_accumulate brackets every x-pass
  * and y-pass launch with HIP events recorded on `stream` (the first 4096 launch pairs of a call)

@@ -137,10 +137,10 @@ def epsilon_n(deltaK, pixelSize, wavelength):
 
 
 def last_plan():
-    arr = (c_int64 * 12)()
+    arr = (c_int64 * 16)()
     lib().litho_abbe_last_plan(arr)
     keys = ("general", "box_row0", "box_col0", "box_rows", "box_cols", "batch", "launches", "variant",
-            "planes_in_flight", "groups_per_plane", "xchunk", "fused_xpass")
+            "planes_in_flight", "groups_per_plane", "xchunk", "fused_xpass", "coarse_grid")
     return dict(zip(keys, list(arr)))
 
 

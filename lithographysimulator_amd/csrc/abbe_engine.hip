@@ -49,10 +49,16 @@ __global__ void k_twiddle_table(float2* tab, int N)
 }
 
 // plan words: [0]=min row,[1]=max row,[2]=min col,[3]=max col of non-zero pupil samples
-//             [4]=min dy,[5]=max dy,[6]=min dx,[7]=max dx
+//             [4]=min dy,[5]=max dy,[6]=min dx,[7]=max dx, [8]=source-point count
+//             [9],[10]=min/max ROW with a non-zero sample on the columns c +- pn/4 (the edges of the natural support box),
+//             [11],[12]=min/max COLUMN with a non-zero sample on the rows c +- pn/4, [13]=1 if a corner of that box is set
+static constexpr int PLAN_WORDS = 14;
 __global__ void k_plan_init(int* plan)
 {
     if (threadIdx.x < 8) plan[threadIdx.x] = (threadIdx.x & 1) ? INT_MIN : INT_MAX;
+    if (threadIdx.x == 8) plan[8] = 0;
+    if (threadIdx.x >= 9 && threadIdx.x <= 12) plan[threadIdx.x] = (threadIdx.x & 1) ? INT_MAX : INT_MIN;
+    if (threadIdx.x == 13) plan[13] = 0;
 }
 
 // Bounding box of the non-zero pupil samples over all planes: grid (row blocks, planes), each block scans
@@ -71,6 +77,11 @@ __global__ __launch_bounds__(256) void k_pupil_box(const float2* __restrict__ P,
             if (v.x != 0.f || v.y != 0.f) {
                 rmin = min(rmin, row); rmax = max(rmax, row);
                 cmin = min(cmin, j); cmax = max(cmax, j);
+                const int ce = pn / 2, he = pn / 4;          // edges of the natural box: a handful of samples, direct atomics
+                const bool ecol = (j == ce + he || j == ce - he), erow = (row == ce + he || row == ce - he);
+                if (ecol) { atomicMin(&plan[9], row); atomicMax(&plan[10], row); }
+                if (erow) { atomicMin(&plan[11], j); atomicMax(&plan[12], j); }
+                if (ecol && erow) atomicExch(&plan[13], 1);
             }
         }
     }
@@ -140,16 +151,135 @@ __global__ void k_slab_reduce(const float* __restrict__ slab, float* __restrict_
     }
 }
 
+static constexpr int COARSE_PLANES = 4;                      // = the largest plane chunk
+static constexpr int EDGE_MAX = 128;                         // longest box-edge support the coarse path handles
+static constexpr int GAM_CHUNKS = 1024;                      // workgroups (partial sums) of k_nyquist_edges
+static constexpr size_t GAM_PARTIAL = (size_t)GAM_CHUNKS * 2 * 2 * EDGE_MAX;      // [chunk][edge][2 * EDGE_MAX]
+static size_t gam_float2(int pn) { return GAM_PARTIAL + 2 * 2 * EDGE_MAX + 2 * (size_t)pn; }
+
+// ----------------------------------------------------------------------------------
+// Coarse-grid path: the Nyquist-line coefficients.
+// The intensity I(q) = sum_s |E_s(q)|^2 has Fourier coefficients C[kappa], |kappa| <= pn/2 (E_s lives on |k| <= pn/4), so
+// pn samples per period -- the coarse grid q = 2 v -- determine it up to the coefficients on the lines kappa_x = +-pn/2
+// and kappa_y = +-pn/2, which alias onto each other there.  Those come only from products of the two opposite edges of
+// the pupil's support box:  Gx[kappa] = sum_s sum_ky A_s[ky, +h] conj(A_s[ky - kappa, -h]),  h = pn/4, and Gy likewise
+// with rows; A_s[k] = P[k] M[k + shift_s].  k_nyquist_edges accumulates them over a chunk of source points per
+// workgroup (deterministic partial sums), k_nyquist_profiles sums the partials and evaluates
+// Gprof[q] = sum_kappa Gx[kappa] w_N^(kappa q) (and Hprof from Gy), k_nyquist_apply adds the missing part
+//   dI[qy, qx] = Re(2 i^qx Gprof[qy]) for odd qx  +  Re(2 i^qy Hprof[qx]) for odd qy        (centred q)
+// to the band-limited interpolation of the coarse image.  (Derivation and a numpy check: DESIGN.md.)
+// ----------------------------------------------------------------------------------
+struct EdgeGeom {
+    int pn, c, h;            // grid, centre, half-width of the natural box
+    int lo[2], len[2];       // edge 0: columns c +- h, support rows lo[0] .. lo[0] + len[0]; edge 1: rows c +- h, support columns
+};
+
+__global__ __launch_bounds__(256) void k_nyquist_edges(const float2* __restrict__ P, const float2* __restrict__ M,
+                                                       const int* __restrict__ shifts, long long S, EdgeGeom eg,
+                                                       float2* __restrict__ partial)
+{
+    __shared__ float2 su[2][EDGE_MAX], sv[2][EDGE_MAX];
+    const int t = threadIdx.x;
+    const int edge = t >> 7, lt = t & 127;                     // threads 0..127: edge 0 (kappa and loads), 128..255: edge 1
+    const int len = eg.len[edge], lo = eg.lo[edge];
+    const long long per = (S + gridDim.x - 1) / gridDim.x;
+    const long long s0 = (long long)blockIdx.x * per, s1 = min(S, s0 + per);
+    // this thread owns kappa = lt - (len - 1) and kappa + 128 ... : at most 2 len - 1 <= 255 values -> two per thread
+    float2 acc0 = make_float2(0.f, 0.f), acc1 = make_float2(0.f, 0.f);
+    const int k0 = lt - (len - 1), k1 = k0 + 128;
+    float2 pu = make_float2(0.f, 0.f), pvv = make_float2(0.f, 0.f);
+    if (lt < len) {                                             // pupil samples on the two opposite edges (fixed per thread)
+        const int i = lo + lt;
+        pu = edge == 0 ? P[(size_t)i * eg.pn + eg.c + eg.h] : P[(size_t)(eg.c + eg.h) * eg.pn + i];
+        pvv = edge == 0 ? P[(size_t)i * eg.pn + eg.c - eg.h] : P[(size_t)(eg.c - eg.h) * eg.pn + i];
+    }
+    for (long long s = s0; s < s1; ++s) {
+        const int dy = shifts[2 * s], dx = shifts[2 * s + 1];
+        __syncthreads();
+        if (lt < len) {
+            const int i = lo + lt;
+            const float2 mu = edge == 0 ? M[(size_t)(i + dy) * eg.pn + eg.c + eg.h + dx] : M[(size_t)(eg.c + eg.h + dy) * eg.pn + i + dx];
+            const float2 mv = edge == 0 ? M[(size_t)(i + dy) * eg.pn + eg.c - eg.h + dx] : M[(size_t)(eg.c - eg.h + dy) * eg.pn + i + dx];
+            su[edge][lt] = cmul(pu, mu);
+            sv[edge][lt] = cmul(pvv, mv);
+        }
+        __syncthreads();
+        for (int i = 0; i < len; ++i) {                        // sum_i u[i] conj(v[i - kappa])
+            const float2 u = su[edge][i];
+            const int j0 = i - k0, j1 = i - k1;
+            if (j0 >= 0 && j0 < len) { const float2 v = sv[edge][j0]; acc0.x += u.x * v.x + u.y * v.y; acc0.y += u.y * v.x - u.x * v.y; }
+            if (j1 >= 0 && j1 < len) { const float2 v = sv[edge][j1]; acc1.x += u.x * v.x + u.y * v.y; acc1.y += u.y * v.x - u.x * v.y; }
+        }
+    }
+    float2* out = partial + ((size_t)blockIdx.x * 2 + edge) * (2 * EDGE_MAX);
+    out[lt] = acc0;                                             // index = kappa + (len - 1)
+    out[lt + 128] = acc1;
+}
+
+// gam layout: [GAM_PARTIAL partials][Gamma: 2 edges x 2 EDGE_MAX][profiles: 2 x pn]
+__global__ void k_nyquist_reduce(float2* __restrict__ gam, int chunks)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // edge * 2 EDGE_MAX + kappa index
+    if (idx >= 2 * 2 * EDGE_MAX) return;
+    float2 a = make_float2(0.f, 0.f);
+    for (int ch = 0; ch < chunks; ++ch) {
+        const float2 v = gam[(size_t)ch * (2 * 2 * EDGE_MAX) + idx];
+        a.x += v.x; a.y += v.y;
+    }
+    gam[GAM_PARTIAL + idx] = a;
+}
+
+__global__ void k_nyquist_profiles(float2* __restrict__ gam, const float2* __restrict__ twtab, EdgeGeom eg, int N)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;        // pixel index; centred coordinate q - c
+    const int edge = blockIdx.y;
+    if (q >= eg.pn) return;
+    const float2* G = gam + GAM_PARTIAL + (size_t)edge * (2 * EDGE_MAX);
+    const int len = eg.len[edge], qc = q - eg.c;
+    float2 a = make_float2(0.f, 0.f);
+    for (int i = 0; i < 2 * len - 1; ++i) {
+        const int kappa = i - (len - 1);
+        const float2 w = twtab[(unsigned)(kappa * qc) & (unsigned)(N - 1)];   // w_N^(kappa q), two's-complement wrap
+        const float2 gk = G[i];
+        a.x += gk.x * w.x - gk.y * w.y;
+        a.y += gk.x * w.y + gk.y * w.x;
+    }
+    gam[GAM_PARTIAL + 2 * 2 * EDGE_MAX + (size_t)edge * eg.pn + q] = a;
+}
+
+__global__ void k_nyquist_apply(float* __restrict__ img, const float2* __restrict__ gam, int pn)
+{
+    const int qx = blockIdx.x * blockDim.x + threadIdx.x, qy = blockIdx.y;
+    if (qx >= pn) return;
+    const int c = pn / 2, cx = qx - c, cy = qy - c;
+    const float2* Gp = gam + GAM_PARTIAL + 2 * 2 * EDGE_MAX;     // Gprof[qy] (edge 0), Hprof[qx] (edge 1)
+    float d = 0.f;
+    if (cx & 1) {                                               // Re(2 i^cx G): i^1 = i -> -2 Im, i^3 = -i -> +2 Im
+        const float2 G = Gp[qy];
+        d += ((cx & 3) == 1 ? -2.f : 2.f) * G.y;
+    }
+    if (cy & 1) {
+        const float2 H = Gp[pn + qx];
+        d += ((cy & 3) == 1 ? -2.f : 2.f) * H.y;
+    }
+    if (d != 0.f) img[(size_t)qy * pn + qx] += d;
+}
+
 // ----------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------
 struct Workspace {
     int* plan;          // 64 ints
     float2* twtab;      // N
+    float2* twtab2;     // pn: table of the coarse-grid transforms
     float* slab;        // G_MAX * nt*4 * pn
+    float* ic;          // coarse-grid intensity of the planes in flight: COARSE_PLANES * pn * pn
+    float2* chat;       // its spectrum: pn * pn
+    float2* gam;        // Nyquist-line work area: partial sums, Gamma, profiles (GAM_FLOAT2 entries)
     float2* T;          // remainder
     size_t t_bytes;
 };
+
 
 // y-pass groups = private partial images (slabs).  Up to 8 for large images; small images can afford more
 // (their y-pass grid would otherwise be a handful of workgroups): as many as fit in 128 MiB, at most 64.
@@ -180,7 +310,11 @@ static size_t workspace_bytes(int pn, int N)
     const size_t nt = (pn + 3) / 4;
     size_t b = 256;
     b += align_up((size_t)N * sizeof(float2), 256);
+    b += align_up((size_t)pn * sizeof(float2), 256);
     b += align_up((size_t)g_cap(pn) * nt * 4 * pn * sizeof(float), 256);
+    b += align_up((size_t)COARSE_PLANES * pn * pn * sizeof(float), 256);
+    b += align_up((size_t)pn * pn * sizeof(float2), 256);
+    b += align_up(gam_float2(pn) * sizeof(float2), 256);
     b += align_up(t_budget(pn), 256);
     return b;
 }
@@ -192,7 +326,11 @@ static bool carve(void* ws, size_t bytes, int pn, int N, Workspace& w)
     unsigned char* p = (unsigned char*)ws;
     w.plan = (int*)p; p += 256;
     w.twtab = (float2*)p; p += align_up((size_t)N * sizeof(float2), 256);
+    w.twtab2 = (float2*)p; p += align_up((size_t)pn * sizeof(float2), 256);
     w.slab = (float*)p; p += align_up((size_t)g_cap(pn) * nt * 4 * pn * sizeof(float), 256);
+    w.ic = (float*)p; p += align_up((size_t)COARSE_PLANES * pn * pn * sizeof(float), 256);
+    w.chat = (float2*)p; p += align_up((size_t)pn * pn * sizeof(float2), 256);
+    w.gam = (float2*)p; p += align_up(gam_float2(pn) * sizeof(float2), 256);
     w.T = (float2*)p;
     w.t_bytes = t_budget(pn);
     return true;
@@ -216,7 +354,7 @@ static int env_int(const char* name, int dflt)
 
 // Tuning / test knobs.  Read ONCE per C-ABI call (the parity tests flip them between calls), never per launch.
 struct Knobs {
-    int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk, xsplit, rect, xrect;
+    int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk, xsplit, rect, xrect, coarse;
     static Knobs read()
     {
         Knobs k;
@@ -233,11 +371,12 @@ struct Knobs {
         k.xsplit = env_int("LITHO_ABBE_XSPLIT", 1);
         k.rect = env_int("LITHO_ABBE_RECT", 1);
         k.xrect = env_int("LITHO_ABBE_XRECT", 1);
+        k.coarse = env_int("LITHO_ABBE_COARSE", 1);
         return k;
     }
 };
 
-static thread_local int64_t g_last_plan[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+static thread_local int64_t g_last_plan[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 // Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's
 // roofline leg).  Off by default: the events serialise nothing but cost host time.
@@ -270,10 +409,10 @@ static int pick_variant(const PassGeom& g, const Knobs& kn)
     return kn.force_generic ? -1 : rl;
 }
 
-// Reads the 9 plan words back (one small synchronising copy).
-static int read_plan(const Workspace& w, int host[9], hipStream_t st)
+// Reads the plan words back (one small synchronising copy).
+static int read_plan(const Workspace& w, int host[PLAN_WORDS], hipStream_t st)
 {
-    HIP_TRY(hipMemcpyAsync(host, w.plan, 9 * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(host, w.plan, PLAN_WORDS * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return LITHO_OK;
 }
@@ -342,7 +481,7 @@ struct AbbePlan {
 };
 
 // pl = the 9 plan words read back from the device (pupil box, shift extents, count)
-static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const int pl[9], int pn, int N, int planes)
+static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const int pl[PLAN_WORDS], int pn, int N, int planes)
 {
     int r0 = pl[0], h = pl[1] - pl[0] + 1, c0 = pl[2], wdt = pl[3] - pl[2] + 1;
     const bool nowrap = (r0 + pl[4] >= 0) && (r0 + h - 1 + pl[5] <= pn - 1) &&
@@ -451,6 +590,95 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
     return LITHO_OK;
 }
 
+// One chunk of planes (pc <= pp.PC pupils starting at Pc) over the whole source list: slabs zeroed, x-pass / y-pass
+// launch pairs batch by batch, slabs reduced INTO dst[0 .. pc) (each pn x pn, accumulated).
+static int accumulate_chunk(const AbbePlan& pp, const SizeOps* ops, const Workspace& w, const float2* twtab,
+                            const float2* M, const float2* Pc, int pc, const int* shifts, int64_t S, int pn, float* dst,
+                            hipStream_t st, MarkList& marks, int64_t& nx)
+{
+    const PassGeom& g = pp.g;
+    const int variant = pp.variant, G = pp.G, xchunk = pp.xchunk;
+    const int64_t bs = pp.bs;
+    const size_t slab_plane = (size_t)g.nt * 4 * pn, plane_elems = (size_t)pn * pn;
+    HIP_TRY(hipMemsetAsync(w.slab, 0, (size_t)pc * G * slab_plane * sizeof(float), st));
+    bool fresh = true;                                     // start a new timing interval after memset / reduce
+    for (int64_t s0 = 0; s0 < S; s0 += bs) {
+        const int nb = (int)((S - s0 < bs) ? (S - s0) : bs);
+        const int* sh = shifts + 2 * s0;
+        if (fresh) { marks.add(-1, 0); fresh = false; }
+        // ---- x-pass: T item (plane q of the chunk, point s) = q * nb + s
+        for (int q = 0; q < pc;) {
+            const float2* Pq = Pc + (size_t)q * plane_elems;
+            float2* Tq = w.T + (size_t)q * nb * g.t_point;
+            int np = 1;
+            if (pp.rect_x) {
+                HIP_TRY(ops->xpass_rect(Pq, M, sh, Tq, twtab, g, nb, xchunk, st));
+            } else if (pp.split_x) {
+                HIP_TRY(ops->xpass_split(Pq, M, sh, Tq, twtab, g, nb, xchunk, st));
+            } else if (pp.fused_x) {
+                np = variant == 0 ? 1 : (pc - q >= 4) ? 4 : (pc - q >= 2 ? 2 : 1);
+                HIP_TRY(ops->xpass_abbe(variant, np, Pq, M, sh, Tq, twtab, g, nb, xchunk, st));
+            } else if (pp.general) {
+                AbbeLoader ld{Pq, M, sh, nullptr, nullptr, 0, 0};
+                HIP_TRY(ops->xpass_general(ld, Tq, twtab, g, nb, st));
+            } else if (variant >= 0) {
+                HIP_TRY(ops->xpass_w64(Pq, M, sh, Tq, twtab, g, nb, st));
+            } else {
+                HIP_TRY(ops->xpass_abbe(-1, 1, Pq, M, sh, Tq, twtab, g, nb, xchunk, st));
+            }
+            q += np;
+        }
+        marks.add(0, nb * pc);
+        // ---- y-pass: every plane of the chunk, G groups each (fewer when the batch is shorter than G)
+        const int Geff = nb < G ? nb : G;
+        if (pp.wave_y) HIP_TRY(ops->ypass_w64(w.T, w.slab, twtab, g, nb, pc, Geff, G, st));
+        else HIP_TRY(ops->ypass_acc(variant, w.T, w.slab, twtab, g, nb, pc, Geff, G, st));
+        marks.add(1, nb * pc);
+        ++nx;
+    }
+    hipLaunchKernelGGL(k_slab_reduce, dim3((pn + 31) / 32, (pn + 31) / 32, pc), dim3(256), 0, st,
+                       w.slab, dst, pn, g.nt * 4, G, G);
+    HIP_TRY(hipGetLastError());
+    return LITHO_OK;
+}
+
+// Coarse-grid reconstruction of ONE plane: out += I(q) on the fine grid, from the coarse image ic (pn x pn samples
+// at q = 2 v over the whole period) and the exact Nyquist-line coefficients.
+//   1. Chat = centred forward DFT2 of ic                    (pn-point transforms: ops_c / twtab2)
+//   2. out += Re( sum_kappa Chat[kappa] w_N^(kappa q) ) / pn^2   (N-point zoom transforms: ops / twtab)
+//   3. Gx, Gy from the box edges of P over the whole source list; out += dI (k_nyquist_apply)
+static int reconstruct_plane(const SizeOps* ops, const SizeOps* ops_c, const Workspace& w, const float2* M,
+                             const float2* Pp, const int* shifts, int64_t S, int pn, int N, const EdgeGeom& eg,
+                             const float* ic, float* out, hipStream_t st)
+{
+    // 1. forward transform of the real coarse image (the machinery of the mask-spectrum pre-step, window = everything)
+    PassGeom gf;
+    gf.pn = pn; gf.c = pn / 2; gf.N = pn; gf.nt = (pn + 3) / 4;
+    gf.kx0 = -pn / 2; gf.kx1 = pn / 2; gf.ky0 = gf.kx0; gf.ky1 = gf.kx1;
+    gf.rows = pn; gf.general = 0; gf.rect_off = 0;
+    gf.xmask = slot_mask(pn, gf.kx0, gf.kx1); gf.ymask = gf.xmask;
+    set_tile(gf, gf.rows);
+    RealImageLoader ldr{ic, pn, 0, nullptr};
+    HIP_TRY(ops_c->xpass_real_fwd(ldr, w.T, w.twtab2, gf, st));
+    HIP_TRY(ops_c->ypass_field(-1, w.T, w.chat, w.twtab2, gf, st));
+    // 2. zoom back to the fine grid: pn x pn coefficients, N-point transforms, the pn centred outputs
+    PassGeom gi;
+    make_geom(gi, pn, N, 0, 0, pn, pn, 0, 4);
+    FieldLoader ldf{w.chat, nullptr};
+    HIP_TRY(ops->xpass_field_inv(ldf, w.T, w.twtab, gi, st));
+    HIP_TRY(ops->ypass_addreal(w.T, out, (float)(1.0 / ((double)pn * (double)pn)), w.twtab, gi, st));
+    // 3. the Nyquist lines
+    if (eg.len[0] > 0 || eg.len[1] > 0) {
+        const int chunks = (int)(S < GAM_CHUNKS ? S : GAM_CHUNKS);
+        hipLaunchKernelGGL(k_nyquist_edges, dim3(chunks), dim3(256), 0, st, Pp, M, shifts, (long long)S, eg, w.gam);
+        hipLaunchKernelGGL(k_nyquist_reduce, dim3((2 * 2 * EDGE_MAX + 255) / 256), dim3(256), 0, st, w.gam, chunks);
+        hipLaunchKernelGGL(k_nyquist_profiles, dim3((pn + 255) / 256, 2), dim3(256), 0, st, w.gam, w.twtab, eg, N);
+        hipLaunchKernelGGL(k_nyquist_apply, dim3((pn + 255) / 256, pn), dim3(256), 0, st, out, w.gam, pn);
+        HIP_TRY(hipGetLastError());
+    }
+    return LITHO_OK;
+}
+
 static int abbe_accumulate(const float2* M, const float2* P, int planes, const int* shifts, int64_t S,
                            const int* count_dev, int64_t* count_out, int pn, int N, float* out, void* ws,
                            size_t ws_bytes, hipStream_t st)
@@ -472,7 +700,7 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
                        P, pn, w.plan);
     hipLaunchKernelGGL(k_shift_extents, dim3(256), dim3(256), 0, st, shifts, (long long)S, count_dev, w.plan);
     HIP_TRY(hipGetLastError());
-    int pl[9];
+    int pl[PLAN_WORDS];
     rc = read_plan(w, pl, st);                               // the ONE host wait of the image path
     if (rc) return rc;
     S = pl[8];                                               // = S, or the device-side count of the source list
@@ -482,56 +710,48 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     AbbePlan pp;
     rc = plan_abbe(pp, w, kn, pl, pn, N, planes);
     if (rc) return rc;
-    const PassGeom& g = pp.g;
-    const int variant = pp.variant, G = pp.G, xchunk = pp.xchunk;
-    const int64_t bs = pp.bs;
-    const size_t slab_plane = (size_t)g.nt * 4 * pn, plane_elems = (size_t)pn * pn;
+
+    // Coarse-grid path (N = 2 pn, pupil inside the natural box, no wrapping shift): the source-point loop runs
+    // pn-point transforms on the grid q = 2 v (half the arithmetic per transformed line), the fine image is
+    // reconstructed once per plane.  Needs the full-output wave kernels of size pn, empty box corners and box-edge
+    // supports of at most EDGE_MAX samples; anything else takes the direct path below.
+    AbbePlan pc_plan;
+    const SizeOps* ops_c = nullptr;
+    EdgeGeom eg;
+    bool coarse = kn.coarse && N == 2 * pn && pp.variant == 1 && !pp.general && pl[13] == 0 &&
+                  (pn == 1024 || pn == 2048 || (pn == 4096 && kn.coarse >= 2));
+    if (coarse) {
+        eg.pn = pn; eg.c = pn / 2; eg.h = pn / 4;
+        eg.lo[0] = pl[10] >= pl[9] ? pl[9] : 0;   eg.len[0] = pl[10] >= pl[9] ? pl[10] - pl[9] + 1 : 0;
+        eg.lo[1] = pl[12] >= pl[11] ? pl[11] : 0; eg.len[1] = pl[12] >= pl[11] ? pl[12] - pl[11] + 1 : 0;
+        ops_c = size_ops(ilog2(pn));
+        coarse = ops_c && eg.len[0] <= EDGE_MAX && eg.len[1] <= EDGE_MAX &&
+                 plan_abbe(pc_plan, w, kn, pl, pn, pn, planes) == LITHO_OK && pc_plan.variant == 0 && pc_plan.wave_y &&
+                 pc_plan.PC <= COARSE_PLANES;
+    }
+    const AbbePlan& run = coarse ? pc_plan : pp;
+    const size_t plane_elems = (size_t)pn * pn;
     int64_t nx = 0;
     // profiling: ONE event per kernel-class boundary (E0 x E1 y E2 x E3 ...); consecutive events bracket the
     // launches of one pass over one batch.  (Two events recorded back to back alias on ROCm, so no begin/end pairs.)
     MarkList marks(g_profiling != 0, st);
-    for (int p0 = 0; p0 < planes; p0 += pp.PC) {
-        const int pc = (planes - p0 < pp.PC) ? planes - p0 : pp.PC;
+    if (coarse) hipLaunchKernelGGL(k_twiddle_table, dim3((pn + 255) / 256), dim3(256), 0, st, w.twtab2, pn);
+    for (int p0 = 0; p0 < planes; p0 += run.PC) {
+        const int pc = (planes - p0 < run.PC) ? planes - p0 : run.PC;
         const float2* Pc = P + (size_t)p0 * plane_elems;
-        HIP_TRY(hipMemsetAsync(w.slab, 0, (size_t)pc * G * slab_plane * sizeof(float), st));
-        bool fresh = true;                                     // start a new timing interval after memset / reduce
-        for (int64_t s0 = 0; s0 < S; s0 += bs) {
-            const int nb = (int)((S - s0 < bs) ? (S - s0) : bs);
-            const int* sh = shifts + 2 * s0;
-            if (fresh) { marks.add(-1, 0); fresh = false; }
-            // ---- x-pass: T item (plane q of the chunk, point s) = q * nb + s
-            for (int q = 0; q < pc;) {
-                const float2* Pq = Pc + (size_t)q * plane_elems;
-                float2* Tq = w.T + (size_t)q * nb * g.t_point;
-                int np = 1;
-                if (pp.rect_x) {
-                    HIP_TRY(ops->xpass_rect(Pq, M, sh, Tq, w.twtab, g, nb, xchunk, st));
-                } else if (pp.split_x) {
-                    HIP_TRY(ops->xpass_split(Pq, M, sh, Tq, w.twtab, g, nb, xchunk, st));
-                } else if (pp.fused_x) {
-                    np = variant == 0 ? 1 : (pc - q >= 4) ? 4 : (pc - q >= 2 ? 2 : 1);
-                    HIP_TRY(ops->xpass_abbe(variant, np, Pq, M, sh, Tq, w.twtab, g, nb, xchunk, st));
-                } else if (pp.general) {
-                    AbbeLoader ld{Pq, M, sh, nullptr, nullptr, 0, 0};
-                    HIP_TRY(ops->xpass_general(ld, Tq, w.twtab, g, nb, st));
-                } else if (variant >= 0) {
-                    HIP_TRY(ops->xpass_w64(Pq, M, sh, Tq, w.twtab, g, nb, st));
-                } else {
-                    HIP_TRY(ops->xpass_abbe(-1, 1, Pq, M, sh, Tq, w.twtab, g, nb, xchunk, st));
-                }
-                q += np;
-            }
-            marks.add(0, nb * pc);
-            // ---- y-pass: every plane of the chunk, G groups each (fewer when the batch is shorter than G)
-            const int Geff = nb < G ? nb : G;
-            if (pp.wave_y) HIP_TRY(ops->ypass_w64(w.T, w.slab, w.twtab, g, nb, pc, Geff, G, st));
-            else HIP_TRY(ops->ypass_acc(variant, w.T, w.slab, w.twtab, g, nb, pc, Geff, G, st));
-            marks.add(1, nb * pc);
-            ++nx;
+        if (!coarse) {
+            rc = accumulate_chunk(pp, ops, w, w.twtab, M, Pc, pc, shifts, S, pn, out + (size_t)p0 * plane_elems, st, marks, nx);
+            if (rc) return rc;
+            continue;
         }
-        hipLaunchKernelGGL(k_slab_reduce, dim3((pn + 31) / 32, (pn + 31) / 32, pc), dim3(256), 0, st,
-                           w.slab, out + (size_t)p0 * plane_elems, pn, g.nt * 4, G, G);
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemsetAsync(w.ic, 0, (size_t)pc * plane_elems * sizeof(float), st));
+        rc = accumulate_chunk(pc_plan, ops_c, w, w.twtab2, M, Pc, pc, shifts, S, pn, w.ic, st, marks, nx);
+        if (rc) return rc;
+        for (int q = 0; q < pc; ++q) {
+            rc = reconstruct_plane(ops, ops_c, w, M, Pc + (size_t)q * plane_elems, shifts, S, pn, N, eg,
+                                   w.ic + (size_t)q * plane_elems, out + (size_t)(p0 + q) * plane_elems, st);
+            if (rc) return rc;
+        }
     }
     if (g_profiling) {
         for (int i = 0; i < 8; ++i) g_profile[i] = 0;
@@ -545,13 +765,14 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
                 g_profile[m.kind * 3 + 2] += m.items;
             }
         }
-        g_profile[6] = pp.wave_y ? 1 : 0;
-        g_profile[7] = pp.PC;
+        g_profile[6] = run.wave_y ? 1 : 0;
+        g_profile[7] = run.PC;
     }
-    g_last_plan[0] = pp.general; g_last_plan[1] = pp.r0; g_last_plan[2] = pp.c0; g_last_plan[3] = pp.h;
-    g_last_plan[4] = pp.wdt; g_last_plan[5] = bs; g_last_plan[6] = nx; g_last_plan[7] = variant;
-    g_last_plan[8] = pp.PC; g_last_plan[9] = G; g_last_plan[10] = xchunk;
-    g_last_plan[11] = pp.fused_x ? 1 : (pp.split_x ? 2 : (pp.rect_x ? 3 : 0));
+    g_last_plan[0] = run.general; g_last_plan[1] = run.r0; g_last_plan[2] = run.c0; g_last_plan[3] = run.h;
+    g_last_plan[4] = run.wdt; g_last_plan[5] = run.bs; g_last_plan[6] = nx; g_last_plan[7] = pp.variant;
+    g_last_plan[8] = run.PC; g_last_plan[9] = run.G; g_last_plan[10] = run.xchunk;
+    g_last_plan[11] = run.fused_x ? 1 : (run.split_x ? 2 : (run.rect_x ? 3 : 0));
+    g_last_plan[12] = coarse ? 1 : 0;
     return LITHO_OK;
 }
 
@@ -567,7 +788,7 @@ static int abbe_field(const float2* pf, const float2* M, int pn, int N, float2* 
     hipLaunchKernelGGL(k_plan_init, dim3(1), dim3(64), 0, st, w.plan);
     hipLaunchKernelGGL(k_pupil_box, dim3((pn + BOX_ROWS_PER_BLOCK - 1) / BOX_ROWS_PER_BLOCK, 1), dim3(256), 0, st, pf, pn, w.plan);
     HIP_TRY(hipGetLastError());
-    int pl[9];
+    int pl[PLAN_WORDS];
     rc = read_plan(w, pl, st);
     if (rc) return rc;
     if (pl[1] < pl[0]) {                                      // zero pupil -> zero field
@@ -685,7 +906,7 @@ int litho_abbe_last_profile(double fields_host[8])
     return LITHO_OK;
 }
 
-int litho_abbe_last_plan(int64_t fields_host[12])
+int litho_abbe_last_plan(int64_t fields_host[16])
 {
     if (!fields_host) return LITHO_E_ARG;
     memcpy(fields_host, litho::g_last_plan, sizeof(litho::g_last_plan));

@@ -409,6 +409,14 @@ struct AbbeLoader {
     }
 };
 
+// Loader: a complex pn x pn array used as it is (the coefficient array of the coarse-grid reconstruction).
+struct FieldLoader {
+    const float2* A;         // [pn,pn]
+    const float2* row;
+    __device__ __forceinline__ void begin_line(int, int a, const PassGeom& g) { row = A + (size_t)(g.ky0 + g.c + a) * g.pn; }
+    __device__ __forceinline__ float2 load(int k, const PassGeom& g) const { return row[k + g.c]; }
+};
+
 // Loader: a real image (the bilinearly scaled mask, mask.py:76-81).  Line a / sample k of the
 // padded N x N frame map to img[a + off][k - kx0 + off]; the zero padding (or, when the
 // scaled mask is larger than N, the crop) is expressed by the window and `off` alone.
@@ -632,6 +640,41 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
     }
 }
 
+// y-pass that ADDS scale * Re(field) to a real image (coarse-grid reconstruction: the interpolated intensity).
+template <int LOG2N>
+__global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void k_ypass_addreal(
+    const float2* __restrict__ Tbuf, float* __restrict__ img, float scale, const float2* __restrict__ twtab, PassGeom g)
+{
+    using F = LineFFT<LOG2N, +1>;
+    using LC = Launch<LOG2N>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* smem = reinterpret_cast<float2*>(smem_raw);
+    const int lt = threadIdx.x % F::T, lg = threadIdx.x / F::T;
+    float2* lds = smem + (size_t)lg * LC::NBUF * F::LDS_LINE;
+    typename F::Twiddles tw;
+    F::load_twiddles(tw, twtab, lt, smem + LC::LDS_EXCH, threadIdx.x, LC::THREADS);
+    const int tile = blockIdx.x * LC::L + lg;
+    const bool active = tile < g.nt;
+    int flip = 0;
+    for (int cidx = 0; cidx < 4; ++cidx) {
+        float2 x[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            int k;
+            const bool ok = centred_index(lt + F::T * e, F::N, g.ky0, g.ky1, k) && active;
+            x[e] = ok ? Tbuf[t_offset(g, (unsigned)(k - g.ky0), (unsigned)tile * 4u + cidx)] : make_float2(0.f, 0.f);
+        }
+        F::template run<LC::NBUF>(x, tw, lds, lt, flip);
+        const int qx = tile * 4 + cidx;
+        if (!active || qx >= g.pn) continue;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            int u;
+            if (centred_index(lt + F::T * m, F::N, -g.c, g.pn - g.c, u)) img[(size_t)(u + g.c) * g.pn + qx] += scale * x[m].x;
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------------
 // per-FFT-size launch table (one translation unit per size, see inst_*.hip)
 // ----------------------------------------------------------------------------------
@@ -657,6 +700,10 @@ struct SizeOps {
                             int planes, int G, int gstride, hipStream_t st);
     hipError_t (*ypass_field)(int sign, const float2* T, float2* field, const float2* tw, const PassGeom& g,
                               hipStream_t st);
+    // coarse-grid reconstruction: rows of a complex coefficient array -> T (sign +), then img += scale * Re(field)
+    hipError_t (*xpass_field_inv)(const FieldLoader& ld, float2* T, const float2* tw, const PassGeom& g, hipStream_t st);
+    hipError_t (*ypass_addreal)(const float2* T, float* img, float scale, const float2* tw, const PassGeom& g,
+                                hipStream_t st);
     // wave-per-line passes (y: N = 1024..8192 with pn = N/2, pruned only; x: N = 4096); hipErrorNotSupported otherwise
     hipError_t (*xpass_w64)(const float2* P, const float2* M, const int* shifts, float2* T, const float2* tw,
                             const PassGeom& g, int nb, hipStream_t st);
@@ -798,6 +845,25 @@ struct SizeImpl {
             default: return ya<-1, false>(T, slab, tw, g, nb, planes, G, gstride, st);
         }
     }
+    static hipError_t xpass_field_inv(const FieldLoader& ld, float2* T, const float2* tw, const PassGeom& g, hipStream_t st)
+    {
+        static LdsOnce once;
+        auto kern = k_xpass<LOG2N, +1, FieldLoader>;
+        hipError_t e = set_lds(once, kern, LC::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((g.rows + LC::L - 1) / LC::L, 1), dim3(LC::THREADS), LC::LDS_BYTES, st, ld, T, tw, g);
+        return hipGetLastError();
+    }
+    static hipError_t ypass_addreal(const float2* T, float* img, float scale, const float2* tw, const PassGeom& g,
+                                    hipStream_t st)
+    {
+        static LdsOnce once;
+        auto kern = k_ypass_addreal<LOG2N>;
+        hipError_t e = set_lds(once, kern, LC::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((g.nt + LC::L - 1) / LC::L), dim3(LC::THREADS), LC::LDS_BYTES, st, T, img, scale, tw, g);
+        return hipGetLastError();
+    }
     static hipError_t xpass_w64(const float2* P, const float2* M, const int* shifts, float2* T, const float2* tw,
                                 const PassGeom& g, int nb, hipStream_t st)
     {
@@ -852,7 +918,8 @@ struct SizeImpl {
         static const SizeOps ops{&SizeImpl<L2>::xpass_abbe, &SizeImpl<L2>::xpass_general,            \
                                  &SizeImpl<L2>::xpass_split, &SizeImpl<L2>::xpass_rect,              \
                                  &SizeImpl<L2>::xpass_real_fwd, &SizeImpl<L2>::ypass_acc,            \
-                                 &SizeImpl<L2>::ypass_field, &SizeImpl<L2>::xpass_w64,               \
+                                 &SizeImpl<L2>::ypass_field, &SizeImpl<L2>::xpass_field_inv,         \
+                                 &SizeImpl<L2>::ypass_addreal, &SizeImpl<L2>::xpass_w64,             \
                                  &SizeImpl<L2>::ypass_w64};                                          \
         return &ops;                                                                                 \
     }

@@ -11,6 +11,7 @@ from helpers import (DEMO_AB, NA, PS, TOL_FIELD, TOL_IMAGE_L2, TOL_IMAGE_MAX, WL
                      rel_max, subsample_bitmap)
 
 pytestmark = pytest.mark.gpu
+PUPIL15 = [0, 0, 0, 1, 3, 0, 0, 1, 0, 0, 0.02, 0.03, 0.01, 0.5, 0.2]
 
 
 @pytest.fixture(scope="module")
@@ -254,6 +255,42 @@ def test_whole_image_vs_oracle_at_baseline_sizes(L, dev, pn, K, skind, ab):
     assert img.shape == ref_img.shape and rel_max(img, ref_img) < TOL_IMAGE_MAX
 
 
+@pytest.mark.parametrize("pn,ab", [(1024, [0, 0, 0, 0, 100]), (2048, DEMO_AB), (1024, PUPIL15), (2048, None)])
+def test_coarse_grid_path_agrees_with_direct_path(L, dev, monkeypatch, pn, ab):
+    """Default at 1024^2 / 2048^2 (N = 2 pn): the source-point loop runs pn-point transforms on the coarse grid q = 2 v
+    and the fine image is reconstructed once per plane (band-limited interpolation + exact Nyquist-line correction).
+    It must agree with the direct N-point path to rounding: a few points, many points (several batches), a stack,
+    an accumulate-into-live-buffer call; ideal pupil (real, box edges at their smallest) and a 15-term pupil."""
+    from lithographysimulator_amd import _native as nat
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    pf = L.Pupil(pn, WL, NA, None if ab is None else f16(ab), dev).generatePupilFunction()
+    sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateQuasar(4, -math.pi / 8), pn)
+    K = 150 if pn == 1024 else 40
+    sel = sh[(torch.arange(K, device=dev) * sh.shape[0]) // K]
+    coarse = L.abbeIntensity(mft, pf, sel, N)
+    assert nat.last_plan()["coarse_grid"] == 1 and nat.last_plan()["variant"] == 1
+    direct = _with_env(monkeypatch, L, {"LITHO_ABBE_COARSE": "0"}, lambda: L.abbeIntensity(mft, pf, sel, N))
+    assert nat.last_plan()["coarse_grid"] == 0
+    e = rel_max(coarse.cpu(), direct.cpu())
+    print(f"{pn}^2 coarse-grid vs direct, {K} points: rel-to-max {e:.2e}, rel-L2 {rel_l2(coarse.cpu(), direct.cpu()):.2e}")
+    assert e < 2e-6
+    one = L.abbeIntensity(mft, pf, sel[:1], N).cpu()
+    one_d = _with_env(monkeypatch, L, {"LITHO_ABBE_COARSE": "0"}, lambda: L.abbeIntensity(mft, pf, sel[:1], N).cpu())
+    assert rel_max(one, one_d) < 2e-6
+    live = direct.clone()
+    L.abbeIntensity(mft, pf, sel[:7], N, out=live)               # accumulates into a non-zero caller buffer
+    assert rel_max(live.cpu(), (direct + L.abbeIntensity(mft, pf, sel[:7], N)).cpu()) < 1e-6
+    stack = L.throughFocusPupils(pn, WL, NA, f16(DEMO_AB), [-130.0, 10.0, 170.0], dev)
+    both = L.abbeIntensity(mft, stack, sel[:9], N).cpu()
+    assert nat.last_plan()["coarse_grid"] == 1
+    for k in range(3):
+        d = _with_env(monkeypatch, L, {"LITHO_ABBE_COARSE": "0"}, lambda: L.abbeIntensity(mft, stack[k], sel[:9], N).cpu())
+        assert rel_max(both[k], d) < 2e-6, k
+
+
 # ------------------------------------------------------------------ through-focus stack (G6)
 def test_through_focus_stack(golden, L, dev):
     from lithographysimulator_amd.synthetic import bernoulli_mask
@@ -487,6 +524,11 @@ def _with_env(monkeypatch, L, env, fn):
 
 
 def test_wave_per_line_and_radix16_ypass_agree_2048(L, dev, monkeypatch):
+    monkeypatch.setenv("LITHO_ABBE_COARSE", "0")          # this test is about the kernels of the DIRECT (N = 2 pn) path
+    _test_wave_per_line_and_radix16_ypass_agree_2048(L, dev, monkeypatch)
+
+
+def _test_wave_per_line_and_radix16_ypass_agree_2048(L, dev, monkeypatch):
     """The default y-pass at 2048^2 is the wave-per-line kernel (k_ypass_wave); the radix-16 workgroup
     kernel (k_ypass_acc), the generic runtime-predicated kernels and the general (modular) path must all
     give the same image on the same inputs."""
@@ -519,6 +561,11 @@ def test_wave_per_line_and_radix16_ypass_agree_2048(L, dev, monkeypatch):
 
 
 def test_2048_kernels_agree_1024(L, dev, monkeypatch):
+    monkeypatch.setenv("LITHO_ABBE_COARSE", "0")          # this test is about the kernels of the DIRECT (N = 2 pn) path
+    _test_2048_kernels_agree_1024(L, dev, monkeypatch)
+
+
+def _test_2048_kernels_agree_1024(L, dev, monkeypatch):
     """BASELINE config 2's size (1024^2, N = 2048).  Default y-pass = k_ypass_rect (two adjacent columns per wave, one
     16-byte load per row pair); the S = 32 wave kernel and the radix-16 kernel must give the same image, with 4- and
     8-column T tiles, also for a stack."""

@@ -8,10 +8,10 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-functi
 # No SLP packing: v_pk_*_f32 are not faster than two scalar ops on gfx950 and cost ~100 register moves
 # per transform (and 40-80 VGPRs).
 FFTFLAGS := -fno-signed-zeros -fno-slp-vectorize
-# Wave-level y-pass kernels live in their own translation units (instw_*.hip) so that they can take their own
-# scheduling strategy.  Same-box A/B (us per source point, default vs max-ilp): N = 4096 (k_ypass_wave) 9.21 -> 9.03,
-# N = 2048 1.82 -> 1.80, N = 8192 (k_ypass_pair, barriers) 46.6 -> 51.4: max-ilp for N = 4096 only.
-WAVEFLAGS_12 ?= -mllvm -amdgpu-sched-strategy=max-ilp
+# Wave-level kernels live in their own translation units (instw_*.hip) so that they can take their own scheduling
+# strategy.  Same-box A/B (us per source point, default vs max-ilp): k_ypass_wave<12> 9.21 -> 9.03, but its full-output
+# variant (the coarse-grid path at 4096^2) spills 73 registers under max-ilp against 3 -- so: default everywhere.
+WAVEFLAGS_12 ?=
 # and the N = 8192 split x-pass: 28.5 -> 27.0 us per source point at 4096^2 (the N = 4096 x-pass prefers the default)
 INSTFLAGS_13 ?= -mllvm -amdgpu-sched-strategy=max-ilp
 INST := $(patsubst $(CSRC)/%.hip,build/%.o,$(wildcard $(CSRC)/inst_*.hip))

@@ -500,7 +500,7 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
     const bool w64_ok = (pn * 2 == N) && ((N == 512 && rect_ok) || N == 1024 || N == 2048 || N == 4096 ||
                                           (N == 8192 && kn.w64_8192));   // w64_8192 defaults to 1
     // N = pn (the coarse-grid transform, and pixel sizes that give N = pn): full-output variants of the same kernels
-    const bool full_ok = (pn == N) && (N == 1024 || N == 2048 || N == 4096);
+    const bool full_ok = (pn == N) && (N == 1024 || N == 2048 || N == 4096 || (N == 512 && (kn.tile <= 0 || kn.tile == 8)));
     const bool w64_shape = ((w64_ok && variant == 1) || (full_ok && variant == 0)) && kn.w64;
     // T tile width.  The x-pass's T stores are bound by the memory system's rate for partial-line writes: measured
     // (scripts/ubench/write_bw.hip) 2.2 TB/s for 32-byte granules (4-column tiles), 3.4 TB/s for 64-byte granules
@@ -719,7 +719,7 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     const SizeOps* ops_c = nullptr;
     EdgeGeom eg;
     bool coarse = kn.coarse && N == 2 * pn && pp.variant == 1 && !pp.general && pl[13] == 0 &&
-                  (pn == 1024 || pn == 2048 || (pn == 4096 && kn.coarse >= 2));
+                  (pn == 512 || pn == 1024 || pn == 2048 || pn == 4096);
     if (coarse) {
         eg.pn = pn; eg.c = pn / 2; eg.h = pn / 4;
         eg.lo[0] = pl[10] >= pl[9] ? pl[9] : 0;   eg.len[0] = pl[10] >= pl[9] ? pl[10] - pl[9] + 1 : 0;

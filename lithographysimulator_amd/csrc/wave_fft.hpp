@@ -136,6 +136,27 @@ struct WaveSq {
         static_for<0, S / 8>([&](auto i_) { constexpr int i = decltype(i_)::value; t.row[8 + i] = table[step * l * 8 * i]; });
     }
 
+    // Lane twiddles in a workgroup-shared LDS table instead of registers: entry (i, lane) at tab[i * 64 + lane]
+    // (NTW x 64 float2 = 8 KB for S = 64).  They are then live only during the twiddle stage: the full-output kernels
+    // (64 accumulators per lane) need those 2 NTW registers.
+    static constexpr int TW_LDS_FLOAT2 = NTW * 64;
+    __device__ static __forceinline__ void fill_lane_twiddle_table(float2* tab, const float2* __restrict__ table,
+                                                                   int step, int tid, int nthreads)
+    {
+        for (int i = tid; i < TW_LDS_FLOAT2; i += nthreads) {
+            const int e = i >> 6, l = i & (S - 1);
+            tab[i] = table[e < 8 ? step * l * e : step * l * 8 * (e - 8)];
+        }
+    }
+    // run() with the lane twiddles read from such a table (the caller synchronises the workgroup after filling it)
+    __device__ static __forceinline__ void run_lds_tw(float2 (&x)[S], const float2* tab, float* lds, int lane)
+    {
+        LaneTwiddles tw;
+        asm volatile("" ::: "memory");                 // the table reads stay inside the caller's loop
+        static_for<1, NTW>([&](auto i_) { constexpr int i = decltype(i_)::value; if constexpr (i != 8) tw.row[i] = tab[i * 64 + lane]; });
+        run(x, tw, lds, lane);
+    }
+
     // x: slot j = sample l + S j (natural).  On return slot brev(k2) = bin l + S k2.
     // lds: this wave's LDS_FLOATS floats; lane = 0..63.
     __device__ static __forceinline__ void run(float2 (&x)[S], const LaneTwiddles& tw, float* lds, int lane)

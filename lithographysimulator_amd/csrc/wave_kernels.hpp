@@ -79,7 +79,13 @@ __global__ __launch_bounds__(WaveShape<LOG2N>::THREADS, WaveShape<LOG2N>::MINWAV
     const int colg = unit / D;                               // column inside the workgroup's column group
     float* lds = smem + wv * W::LDS_FLOATS;
     typename W::LaneTwiddles tw;
-    W::load_lane_twiddles(tw, twtab, l, D);                  // w_{S*S}^e is entry D*e of the w_N table
+    float2* twlds = reinterpret_cast<float2*>(smem_raw + WS::LDS_BYTES);      // FULL: lane twiddles in LDS (registers go to acc)
+    if constexpr (FULL) {
+        W::fill_lane_twiddle_table(twlds, twtab, D, threadIdx.x, WS::THREADS);
+        __syncthreads();
+    } else {
+        W::load_lane_twiddles(tw, twtab, l, D);              // w_{S*S}^e is entry D*e of the w_N table
+    }
     const float2 tl = twtab[l * p];                          // w_N^(l p)  (1 for p = 0)
 
     // The tile index is wave-uniform (a wave's units cover at most one tile); readfirstlane makes that
@@ -125,7 +131,8 @@ __global__ __launch_bounds__(WaveShape<LOG2N>::THREADS, WaveShape<LOG2N>::MINWAV
                 x[j] = make_float2(0.f, 0.f);
             }
         });
-        W::run(x, tw, lds, lane);
+        if constexpr (FULL) W::run_lds_tw(x, twlds, lds, lane);
+        else W::run(x, tw, lds, lane);
         // kept bins of the sub-transform: v in [-S*S/4, S*S/4)  ->  k2 in [0, S/4) and [3S/4, S)
         static_for<0, NACC>([&](auto i_) {
             constexpr int i = decltype(i_)::value;
@@ -405,13 +412,14 @@ static hipError_t launch_ypass_wave_tc(const float2* T, float* slab, const float
     if (g.N == g.pn) {                                  // coarse-grid transforms (N = pn): every bin kept
         if constexpr (LOG2N == 12) {
             static LdsOnce once;
+            constexpr size_t ldsf = lds4 + (size_t)WaveSq<6>::TW_LDS_FLOAT2 * sizeof(float2);     // + the lane-twiddle table
             auto kern = k_ypass_wave<LOG2N, TC, true>;
-            hipError_t e = set_lds(once, kern, lds4);
+            hipError_t e = set_lds(once, kern, ldsf);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, 4>(g.pn), planes * G), dim3(256), lds4, st, T, slab, tw, g, nb, G,
+            hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, 4>(g.pn), planes * G), dim3(256), ldsf, st, T, slab, tw, g, nb, G,
                                gstride);
             return hipGetLastError();
-        } else if constexpr (LOG2N == 10 || LOG2N == 11) {
+        } else if constexpr (LOG2N >= 9 && LOG2N <= 11) {
             constexpr int NL = 4096 >> LOG2N;
             if constexpr (NL <= TC) {
                 static LdsOnce once;

@@ -255,7 +255,8 @@ def test_whole_image_vs_oracle_at_baseline_sizes(L, dev, pn, K, skind, ab):
     assert img.shape == ref_img.shape and rel_max(img, ref_img) < TOL_IMAGE_MAX
 
 
-@pytest.mark.parametrize("pn,ab", [(1024, [0, 0, 0, 0, 100]), (2048, DEMO_AB), (1024, PUPIL15), (2048, None)])
+@pytest.mark.parametrize("pn,ab", [(1024, [0, 0, 0, 0, 100]), (2048, DEMO_AB), (1024, PUPIL15), (2048, None),
+                                   (512, DEMO_AB), (4096, [0, 0, 0, 0, 100])])
 def test_coarse_grid_path_agrees_with_direct_path(L, dev, monkeypatch, pn, ab):
     """Default at 1024^2 / 2048^2 (N = 2 pn): the source-point loop runs pn-point transforms on the coarse grid q = 2 v
     and the fine image is reconstructed once per plane (band-limited interpolation + exact Nyquist-line correction).
@@ -268,7 +269,7 @@ def test_coarse_grid_path_agrees_with_direct_path(L, dev, monkeypatch, pn, ab):
     eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
     pf = L.Pupil(pn, WL, NA, None if ab is None else f16(ab), dev).generatePupilFunction()
     sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateQuasar(4, -math.pi / 8), pn)
-    K = 150 if pn == 1024 else 40
+    K = {512: 300, 1024: 150, 2048: 40, 4096: 12}[pn]
     sel = sh[(torch.arange(K, device=dev) * sh.shape[0]) // K]
     coarse = L.abbeIntensity(mft, pf, sel, N)
     assert nat.last_plan()["coarse_grid"] == 1 and nat.last_plan()["variant"] == 1
@@ -371,6 +372,11 @@ def test_config5_stack_at_size_vs_golden(golden, L, dev):
 
 
 def test_stack_plane_chunk_knob_and_generic_variant(L, dev, monkeypatch):
+    monkeypatch.setenv("LITHO_ABBE_COARSE", "0")          # this test is about the kernels of the DIRECT (N = 2 pn) path
+    _test_stack_plane_chunk_knob_and_generic_variant(L, dev, monkeypatch)
+
+
+def _test_stack_plane_chunk_knob_and_generic_variant(L, dev, monkeypatch):
     """Through-focus stacks through the non-fused x-pass variants (generic kernels, general/wrapping path) and with
     other plane-chunk sizes must agree with the fused default."""
     from lithographysimulator_amd import _native as nat
@@ -599,6 +605,11 @@ def _test_2048_kernels_agree_1024(L, dev, monkeypatch):
 
 @pytest.mark.parametrize("pn", [256, 512])
 def test_small_size_kernels_agree(L, dev, monkeypatch, pn):
+    monkeypatch.setenv("LITHO_ABBE_COARSE", "0")          # this test is about the kernels of the DIRECT (N = 2 pn) path
+    _test_small_size_kernels_agree(L, dev, monkeypatch, pn)
+
+
+def _test_small_size_kernels_agree(L, dev, monkeypatch, pn):
     """N = 512 / 1024 (pn = 256 / 512): default y-pass = k_ypass_rect with 8 / 4 adjacent columns per wave; the
     radix-16 kernels (and, at N = 1024, the S = 32 wave kernel) must agree, and so must the CPU oracle."""
     from lithographysimulator_amd import _native as nat
@@ -627,6 +638,11 @@ def test_small_size_kernels_agree(L, dev, monkeypatch, pn):
 
 
 def test_8192_kernels_agree_4096(L, dev, monkeypatch):
+    monkeypatch.setenv("LITHO_ABBE_COARSE", "0")          # this test is about the kernels of the DIRECT (N = 2 pn) path
+    _test_8192_kernels_agree_4096(L, dev, monkeypatch)
+
+
+def _test_8192_kernels_agree_4096(L, dev, monkeypatch):
     """BASELINE config 4's size (4096^2, N = 8192).  Default = k_xpass_split (each row as two 4096-point transforms,
     16-byte T stores) + k_ypass_pair (a pair of waves per column).  The 8192-point radix-16 engine kernels they
     replace must give the same image, in every combination, also for a through-focus stack."""

@@ -208,6 +208,15 @@ def main():
     lines = {"xpass": plan["box_rows"], "ypass": pn}            # lines transformed per T item
     n_exec = pn if plan.get("coarse_grid") else N                # coarse-grid path: pn-point transforms on the grid q = 2 v
     line_flops = 5.0 * n_exec * math.log2(n_exec)                # nominal FFT flops of one transformed line
+    # the kernels' names as rocprofv3 prints them (profiles/*_kernel_stats.csv), from the plan the library reports
+    l2, full = int(math.log2(n_exec)), ", true" if n_exec == pn else ""
+    if prof["ypass_kernel"] == "k_ypass_wave":
+        yname = ("k_ypass_pair<13, 8>" if l2 == 13 else f"k_ypass_wave<12, 8{full}>" if l2 == 12
+                 else f"k_ypass_rect<{l2}, 8{full}>")
+    else:
+        yname = "k_ypass_acc"
+    xname = {1: f"k_xpass_abbe<{l2}, {int(math.log2(n_exec // pn))}, true, 1>", 2: "k_xpass_split<13>",
+             3: f"k_xpass_rect<{l2}{', true' if full else ''}>"}.get(plan.get("fused_xpass"), "k_xpass")
     kern = {}
     for k in ("xpass", "ypass"):
         launches = max(1, prof[f"{k}_launches"])
@@ -238,7 +247,7 @@ def main():
     both_flops = sum(kern[k]["nominal_flops_per_launch"] * kern[k]["launches"] for k in kern)
     eff40 = 40.0 * pn * pn * prof["ypass_points"] / (both_ms * 1e-3) / 1e9 if both_ms else 0.0
     dom_s = kern[dom]["avg_launch_ms"] * 1e-3
-    roofline = {"bound": "valu", "kernel": prof["ypass_kernel"] if dom == "ypass" else "k_xpass_abbe",
+    roofline = {"bound": "valu", "kernel": yname if dom == "ypass" else xname,
                 "achieved": kern[dom]["achieved_TFLOPs"], "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": kern[dom]["achieved_TFLOPs"] / VALU_PEAK_TFLOPS, "traffic": traffic,
                 "avg_launch_ms": kern[dom]["avg_launch_ms"],

@@ -533,8 +533,11 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
     // plane its own groups and slabs.  The T buffer of a launch pair holds PC x batch items for the planes in
     // flight.  The gather was never the x-pass's limit (its T stores are): PC = 2 takes 40 % of the x-pass's load
     // instructions away at equal x-pass time, but its 2 x batch items of T leave the Infinity Cache and the y-pass
-    // pays 4-5 % for that (2-3 % of the total against plane-by-plane).  LITHO_ABBE_PLANE_CHUNK overrides.
-    int PC = planes < 2 ? planes : 2;
+    // pays 4-5 % for that (2-3 % of the total against plane-by-plane); on the coarse-grid path, whose y-pass is twice
+    // as fast, it pays 26 % (2048^2 x 8 planes, us per point and plane: PC = 1 9.42 / 9.53, PC = 2 10.82 / 10.83,
+    // PC = 4 with a quarter of the batch 12.7).  Default: plane by plane; LITHO_ABBE_PLANE_CHUNK = 2 / 4 selects the
+    // fused launches (parity-tested).
+    int PC = planes < 1 ? planes : 1;
     if (kn.plane_chunk > 0) PC = kn.plane_chunk < planes ? kn.plane_chunk : planes;
     if (PC > g_cap(pn)) PC = g_cap(pn);
 
@@ -581,8 +584,11 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
     // point, radix-16 x-pass -> k_xpass_rect): N = 1024 0.57 -> 0.36, N = 2048 1.43 -> 1.46, N = 512 0.27 -> 0.26: its
     // loads are not prefetched (no registers left), so it only pays where the radix-16 engine is at its weakest.
     // LITHO_ABBE_XRECT: 0 off, 1 N = 1024 only (default), 2 every N <= 2048 (parity tests).
-    pp.rect_x = !general && variant == 1 && pn * 2 == N && N >= 512 && N <= 2048 && g.tcl == 3 &&
-                (kn.xrect >= 2 || (kn.xrect == 1 && N == 1024));
+    // The same kernel with every bin kept serves the coarse-grid transforms (variant 0, N = pn) -- only on request:
+    // with twice the loads and stores per wave it is SLOWER than the radix-16 x-pass at every size (coarse-grid x-pass,
+    // us per point, radix-16 -> rect: N' = 512 0.28 -> 0.32, 1024 1.25 -> 1.49, 2048 4.73 -> 6.77).
+    pp.rect_x = !general && ((variant == 1 && pn * 2 == N) || (variant == 0 && pn == N)) && N >= 512 && N <= 2048 &&
+                g.tcl == 3 && (kn.xrect >= 2 || (kn.xrect == 1 && variant == 1 && N == 1024));
     const bool wave_x_optin = wave_y && variant == 1 && N == 4096 && kn.w64x && g.tcl == 2;      // k_xpass_w64 (slower, parity-tested)
     pp.fused_x = !pp.split_x && !pp.rect_x && !general && variant >= 0 && !wave_x_optin;
     pp.general = general; pp.variant = variant; pp.r0 = r0; pp.c0 = c0; pp.h = h; pp.wdt = wdt;

@@ -317,14 +317,16 @@ __global__ __launch_bounds__(256, 2) void k_ypass_rect(
 // instruction writes WHOLE 128-byte lines (measured 4.2-4.3 TB/s against 3.4 for the 64-byte granules of the
 // one-row-per-workgroup x-pass, scripts/ubench/write_bw.hip L0/L1).  No workgroup barriers.
 // ----------------------------------------------------------------------------------
-template <int LOG2N>
+template <int LOG2N, bool FULL = false>
 __global__ __launch_bounds__(256, 2) void k_xpass_rect(
     const float2* __restrict__ P, const float2* __restrict__ M, const int* __restrict__ shifts,
     float2* __restrict__ Tbuf, const float2* __restrict__ twtab, PassGeom g, int nb, int chunk)
 {
     static_assert(LOG2N >= 9 && LOG2N <= 11, "multi-row-per-wave x-pass: N = 512, 1024, 2048");
     using W = WaveSq<6>;
-    constexpr int S = 64, N = 1 << LOG2N, NL = (S * S) / N, H = S / NL, JL = H / 8, TC = 8;
+    // FULL: N = pn (coarse-grid transforms): half of the samples live, every bin kept
+    constexpr int S = 64, N = 1 << LOG2N, NL = (S * S) / N, H = S / NL, JL = FULL ? H / 4 : H / 8, TC = 8;
+    constexpr int NOUT = FULL ? S : S / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);
     const int lane = threadIdx.x & 63;
@@ -373,9 +375,9 @@ __global__ __launch_bounds__(256, 2) void k_xpass_rect(
         W::template run_rect<NL>(x, tw, lds, lane);
         const __amdgpu_buffer_rsrc_t rT =
             make_rsrc(Tbuf + (size_t)s * g.t_point, (size_t)g.t_point * sizeof(float2));
-        static_for<0, S / 2>([&](auto i_) {
+        static_for<0, NOUT>([&](auto i_) {
             constexpr int i = decltype(i_)::value;
-            constexpr int k2 = i < S / 4 ? i : S / 2 + i;
+            constexpr int k2 = FULL ? i : (i < S / 4 ? i : S / 2 + i);
             constexpr int ub = k2 < S / 2 ? H * k2 : H * k2 - N;            // u - m
             const unsigned tile_off = (unsigned)((ub + g.c) >> 3) * rowstride;
             buf_store_c64(rT, obase == BUF_OOB ? BUF_OOB : obase + tile_off, x[W::brev(k2)]);
@@ -392,12 +394,20 @@ hipError_t launch_xpass_rect(const float2* P, const float2* M, const int* shifts
         static LdsOnce once;
         constexpr size_t lds = 4 * WaveSq<6>::LDS_FLOATS * sizeof(float);
         constexpr int NL = 4096 >> LOG2N;
+        const int groups = (g.rows + NL - 1) / NL;
+        const dim3 grid((groups + 3) / 4, (nb + chunk - 1) / chunk);
+        if (g.N == g.pn) {
+            static LdsOnce once_full;
+            auto kern = k_xpass_rect<LOG2N, true>;
+            hipError_t e = set_lds(once_full, kern, lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, P, M, shifts, T, tw, g, nb, chunk);
+            return hipGetLastError();
+        }
         auto kern = k_xpass_rect<LOG2N>;
         hipError_t e = set_lds(once, kern, lds);
         if (e != hipSuccess) return e;
-        const int groups = (g.rows + NL - 1) / NL;
-        hipLaunchKernelGGL(kern, dim3((groups + 3) / 4, (nb + chunk - 1) / chunk), dim3(256), lds, st, P, M, shifts, T, tw,
-                           g, nb, chunk);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, P, M, shifts, T, tw, g, nb, chunk);
         return hipGetLastError();
     } else {
         return hipErrorNotSupported;

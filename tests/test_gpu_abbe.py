@@ -292,6 +292,29 @@ def test_coarse_grid_path_agrees_with_direct_path(L, dev, monkeypatch, pn, ab):
         assert rel_max(both[k], d) < 2e-6, k
 
 
+@pytest.mark.parametrize("pn", [512, 1024, 2048])
+def test_coarse_grid_xpass_kernels_agree(L, dev, monkeypatch, pn):
+    """The coarse-grid row pass has two kernels (radix-16 workgroup-per-row, several-rows-per-wave with whole-line
+    stores): both must give the same image, ragged last row group and several batches included."""
+    from lithographysimulator_amd import _native as nat
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    pf = L.Pupil(pn, WL, NA, f16(DEMO_AB), dev).generatePupilFunction()
+    sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateQuasar(4, -math.pi / 8), pn)
+    K = {512: 300, 1024: 150, 2048: 40}[pn]
+    sel = sh[(torch.arange(K, device=dev) * sh.shape[0]) // K]
+    imgs = {}
+    for xr in ("0", "2"):
+        imgs[xr] = _with_env(monkeypatch, L, {"LITHO_ABBE_XRECT": xr}, lambda: L.abbeIntensity(mft, pf, sel, N)).cpu()
+        plan = nat.last_plan()
+        assert plan["coarse_grid"] == 1 and plan["fused_xpass"] == (3 if xr == "2" else 1), plan
+    assert rel_max(imgs["0"], imgs["2"]) < 1e-6
+    direct = _with_env(monkeypatch, L, {"LITHO_ABBE_COARSE": "0"}, lambda: L.abbeIntensity(mft, pf, sel, N)).cpu()
+    assert rel_max(imgs["2"], direct) < 2e-6
+
+
 # ------------------------------------------------------------------ through-focus stack (G6)
 def test_through_focus_stack(golden, L, dev):
     from lithographysimulator_amd.synthetic import bernoulli_mask
@@ -336,7 +359,7 @@ def test_config5_stack_at_size_vs_golden(golden, L, dev):
     shifts = torch.from_numpy(g["shifts"]).to(dev)
     raw = L.abbeIntensity(mft, stack, shifts, N)
     plan = nat.last_plan()
-    assert plan["fused_xpass"] == 1 and plan["planes_in_flight"] == 2 and plan["variant"] == 1
+    assert plan["fused_xpass"] == 1 and plan["planes_in_flight"] == 1 and plan["variant"] == 1
     assert raw.shape == (32, pn, pn)
     img = L.postProcess(raw, eps)
     assert tuple(img.shape[1:]) == tuple(g["final_shape"])
@@ -361,14 +384,15 @@ def test_config5_stack_at_size_vs_golden(golden, L, dev):
     for j in range(7):
         assert rel_max(part[j], raw[4 + j]) < 1e-6, j
     import os
-    os.environ["LITHO_ABBE_PLANE_CHUNK"] = "4"
-    try:
-        four = L.abbeIntensity(mft, stack[8:16], shifts, N).cpu()
-        assert nat.last_plan()["planes_in_flight"] == 4
-    finally:
-        del os.environ["LITHO_ABBE_PLANE_CHUNK"]
-    for j in range(8):
-        assert rel_max(four[j], raw[8 + j]) < 1e-6, j
+    for pc in ("4", "2"):
+        os.environ["LITHO_ABBE_PLANE_CHUNK"] = pc
+        try:
+            fused = L.abbeIntensity(mft, stack[8:15], shifts, N).cpu()
+            assert nat.last_plan()["planes_in_flight"] == int(pc)
+        finally:
+            del os.environ["LITHO_ABBE_PLANE_CHUNK"]
+        for j in range(7):
+            assert rel_max(fused[j], raw[8 + j]) < 1e-6, (pc, j)
 
 
 def test_stack_plane_chunk_knob_and_generic_variant(L, dev, monkeypatch):

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round profile capture on the GPU box: bench lines, rocprofv3 kernel-trace stats of the SAME default command, PMC
+# Round profile capture on the GPU box (two steps: a full run, copy traffic_*.json into profiles/traffic.json, then
+# SKIP_PMC=1 so that the bench lines carry the traffic measured for THESE kernels): bench lines, rocprofv3 kernel-trace stats of the SAME default command, PMC
 # passes over bench.py itself (separate counter-only runs).  Usage: scripts/profile_round.sh r02
 R=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -11,7 +12,8 @@ python3 bench.py --workload cfg1 > $O/bench_cfg1.json 2>/dev/null
 python3 bench.py --workload cfg2 > $O/bench_cfg2.json 2>/dev/null
 python3 bench.py --workload cfg4 --shard 0/8 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_cfg4_shard0of8.json 2>/dev/null
 python3 bench.py --workload cfg5 --steps 1 --warmup 0 --no-cpu-baseline > $O/bench_cfg5.json 2>/dev/null
-bash scripts/pmc_traffic.sh $R cfg3 504 cfg2 2016 cfg4 64 cfg5 120 cfg1 3233
+# SKIP_PMC=1: bench lines and kernel stats only (e.g. after profiles/traffic.json has been refreshed from the PMC passes)
+[ -n "$SKIP_PMC" ] || bash scripts/pmc_traffic.sh $R cfg3 504 cfg2 2016 cfg4 64 cfg5 120 cfg1 3233
 # keep the summaries small: the raw per-dispatch CSVs stay in gpurun_out
 find $O -name "*_agent_info.csv" -delete
 ls -la $O

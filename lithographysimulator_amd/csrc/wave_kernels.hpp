@@ -58,6 +58,11 @@ static inline int wave_grid_x(int pn)
 
 // FULL = false: N = 2 pn (half of the bins are kept, a quarter of the inputs live).  FULL = true: N = pn -- the
 // "coarse grid" transform (every bin kept, half of the inputs live; D = 1 only), see k_ypass_rect.
+// The full-output kernel drags 33 64-byte row granules per lane and line through the L1 for 8 useful bytes each, and
+// that traffic -- not the arithmetic -- is its limit: a workgroup barrier per line keeps the four waves of a workgroup
+// (four adjacent columns of one tile) in step, so that the L1 serves three of their four requests for a granule
+// (4096^2, y-pass us per source point: 32.5 free-running, 28.2 with the barrier; one 512-thread workgroup per tile
+// with the barrier: 34.5).  The same barrier costs the half-output and the multi-column kernels 5-10 %.
 template <int LOG2N, int TC, bool FULL = false>
 __global__ __launch_bounds__(WaveShape<LOG2N>::THREADS, WaveShape<LOG2N>::MINWAVES) void k_ypass_wave(
     const float2* __restrict__ Tbuf, float* __restrict__ slab, const float2* __restrict__ twtab,
@@ -109,6 +114,9 @@ __global__ __launch_bounds__(WaveShape<LOG2N>::THREADS, WaveShape<LOG2N>::MINWAV
     auto slot_off = [&](int j) { return vb + (unsigned)(j <= JLIVE ? RB * S * j : RB * S * j - RB * S * S); };
 
     for (int s = grp; s < nb; s += G) {
+#ifndef LITHO_WAVE_FULL_NOSYNC
+        if constexpr (FULL) __builtin_amdgcn_s_barrier();      // the waves of a tile in step: one L1 fill per granule
+#endif
         const __amdgpu_buffer_rsrc_t rT =
             make_rsrc(Tbuf + (size_t)s * g.t_point + (size_t)(active ? tile : 0) * g.rows * TC, tile_bytes);
         float2 x[S];

@@ -56,6 +56,8 @@ static inline int wave_grid_x(int pn)
     else return WPT * (((pn + TC - 1) / TC + 7) / 8 * 8);
 }
 
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+
 // FULL = false: N = 2 pn (half of the bins are kept, a quarter of the inputs live).  FULL = true: N = pn -- the
 // "coarse grid" transform (every bin kept, half of the inputs live; D = 1 only), see k_ypass_rect.
 // The full-output kernel drags 33 64-byte row granules per lane and line through the L1 for 8 useful bytes each, and
@@ -120,6 +122,43 @@ __global__ __launch_bounds__(WaveShape<LOG2N>::THREADS, WaveShape<LOG2N>::MINWAV
         const __amdgpu_buffer_rsrc_t rT =
             make_rsrc(Tbuf + (size_t)s * g.t_point + (size_t)(active ? tile : 0) * g.rows * TC, tile_bytes);
         float2 x[S];
+#ifndef LITHO_WAVE_FULL_NOPAIR
+        if constexpr (FULL && TC == 8) {
+            // Pair loading: waves 2i and 2i+1 own adjacent columns (one 16-byte half of a row granule).  The even wave
+            // loads BOTH columns of the lower live slots with 16-byte loads, the odd wave both columns of the upper
+            // ones; each keeps its own column and hands the other to its partner through the partner's transpose
+            // matrix, which is idle until pass A is done (the barrier at the top of the loop makes sure of that).
+            // Half the load instructions, and every granule is requested once per pair instead of twice.
+            float2* const mine = reinterpret_cast<float2*>(lds);
+            float2* const theirs = reinterpret_cast<float2*>(smem + (wv ^ 1) * W::LDS_FLOATS);
+            const unsigned vbp = vb - (unsigned)(col & 1) * 8u;          // the pair's even column
+            auto pair_off = [&](int j) { return vbp + (unsigned)(j <= JLIVE ? RB * S * j : RB * S * j - RB * S * S); };
+            static_for<JLIVE + 1, S - JLIVE>([&](auto j_) { x[decltype(j_)::value] = make_float2(0.f, 0.f); });
+            const bool even_wave = (__builtin_amdgcn_readfirstlane(wv) & 1) == 0;      // wave-uniform: a scalar branch
+            if (even_wave) {
+                static_for<0, JLIVE + 1>([&](auto j_) {
+                    constexpr int j = decltype(j_)::value;
+                    const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(rT, pair_off(j), 0, 0);
+                    x[j] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+                    theirs[j * 64 + lane] = make_float2(__uint_as_float(v.z), __uint_as_float(v.w));
+                });
+            } else {
+                static_for<S - JLIVE, S>([&](auto j_) {
+                    constexpr int j = decltype(j_)::value;
+                    const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(rT, pair_off(j), 0, 0);
+                    x[j] = make_float2(__uint_as_float(v.z), __uint_as_float(v.w));
+                    theirs[(j - (S - JLIVE)) * 64 + lane] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+                });
+            }
+            __syncthreads();
+            if (even_wave) {
+                static_for<S - JLIVE, S>([&](auto j_) { constexpr int j = decltype(j_)::value; x[j] = mine[(j - (S - JLIVE)) * 64 + lane]; });
+            } else {
+                static_for<0, JLIVE + 1>([&](auto j_) { constexpr int j = decltype(j_)::value; x[j] = mine[j * 64 + lane]; });
+            }
+            asm volatile("" ::: "memory");             // the transposes below reuse `mine`: keep these reads in front of them
+        } else
+#endif
         static_for<0, S>([&](auto j_) {
             constexpr int j = decltype(j_)::value;
             if constexpr (j <= JLIVE || j >= S - JLIVE) {
@@ -235,7 +274,6 @@ __global__ __launch_bounds__(256, 2) void k_ypass_pair(
 // ADJACENT columns per wave (WaveSq<6>::run_rect: 64 lanes x 64/NL slots per line).  A row of the NL columns is
 // 8 NL contiguous bytes of a T tile: NL/2 16-byte loads.  Workgroup = 4 waves = 4 NL columns.
 // ----------------------------------------------------------------------------------
-typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 // FULL = false: N = 2 pn.  FULL = true: N = pn, the COARSE-GRID transform -- the Abbe sum is accumulated on the
 // pn x pn grid q = 2 v that spans the whole period (E_s(2v) = sum_k A_s[k] w_pn^(k v)): every bin is kept
 // (64 accumulators per lane) and |k| <= pn/4 = N/4 of the inputs are live; abbe_engine.hip reconstructs the fine

@@ -484,6 +484,32 @@ def test_full_source_additivity_config2(L, dev):
     assert rel_max((norm * 98832).cpu(), img.cpu()) < 1e-6
 
 
+@pytest.mark.parametrize("pn,kind,S_full", [(1024, "annular", 98832), (2048, "quasar", 198108)])
+def test_full_source_coarse_grid_vs_direct(L, dev, monkeypatch, pn, kind, S_full):
+    """BASELINE configs 2 and 3 at their FULL source lists: the coarse-grid path (pn-point transforms + one
+    reconstruction) against the direct path (N = 2 pn zoom transform per source point) -- two different kernel
+    families and two different summation orders over 1e5 .. 2e5 source points."""
+    from lithographysimulator_amd import _native as nat
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    ls = L.LightSource(0.4, 0.8, pn, NA, device=dev)
+    bm = ls.generateAnnular() if kind == "annular" else ls.generateQuasar(4, -math.pi / 8)
+    pf = L.Pupil(pn, WL, NA, f16([0, 0, 0, 0, 100] if kind == "annular" else DEMO_AB), dev).generatePupilFunction()
+    sh = L.sourceShifts(bm, pn)
+    assert sh.shape[0] == S_full
+    coarse = L.abbeIntensity(mft, pf, sh, N)
+    assert nat.last_plan()["coarse_grid"] == 1
+    direct = _with_env(monkeypatch, L, {"LITHO_ABBE_COARSE": "0"}, lambda: L.abbeIntensity(mft, pf, sh, N))
+    assert nat.last_plan()["coarse_grid"] == 0
+    e = rel_max(coarse.cpu(), direct.cpu())
+    print(f"{pn}^2 full source ({S_full} points): coarse-grid vs direct path rel-to-max {e:.2e}, "
+          f"rel-L2 {rel_l2(coarse.cpu(), direct.cpu()):.2e}")
+    assert e < 2e-6
+    assert float(coarse.min()) >= 0.0 or abs(float(coarse.min())) < 1e-6 * float(coarse.max())   # an intensity
+
+
 def test_async_count_path_edge_cases(L, dev):
     """sourceShiftsAsync + abbeIntensity(count=...): empty source, one point, and agreement with the synchronous list."""
     from lithographysimulator_amd.synthetic import bernoulli_mask

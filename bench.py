@@ -59,8 +59,8 @@ ALGO_BYTES = {"xpass": 24.0, "ypass": 16.0}
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS))
     ap.add_argument("--shard", default=None, metavar="i/n",
                     help="single GPU only: process shard i of n of the source list (the per-rank work of the n-GPU run, "
@@ -205,6 +205,23 @@ def main():
     prof = nat.last_profile()
     plan = nat.last_plan()
     nat.set_profiling(False)
+    # measured device-copy and device-fill ceilings of THIS box (1 GiB, beyond the 256 MiB Infinity Cache): what the
+    # memory system sustains for plain streams, to put next to the 8 TB/s spec the fractions are quoted against
+    copy_gbs = fill_gbs = None
+    try:
+        a = torch.empty(1 << 28, dtype=torch.float32, device=dev); b = torch.empty_like(a)
+        b.copy_(a); a.zero_(); torch.cuda.synchronize()
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        for _ in range(5): b.copy_(a)
+        e1.record()
+        for _ in range(5): a.zero_()
+        e2.record(); torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9      # read + write bytes
+        fill_gbs = 5 * a.numel() * 4 / (e1.elapsed_time(e2) * 1e-3) / 1e9          # write bytes
+        del a, b
+    except Exception:
+        pass
     lines = {"xpass": plan["box_rows"], "ypass": pn}            # lines transformed per T item
     n_exec = pn if plan.get("coarse_grid") else N                # coarse-grid path: pn-point transforms on the grid q = 2 v
     line_flops = 5.0 * n_exec * math.log2(n_exec)                # nominal FFT flops of one transformed line
@@ -259,6 +276,7 @@ def main():
                              "frac": both_flops / (both_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS if both_ms else 0.0,
                              "note": "x-pass + y-pass nominal flops over their summed kernel time"},
                 "hbm": {"peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "measured_copy_ceiling": copy_gbs, "measured_fill_ceiling": fill_gbs,
                         "measured": traffic / dom_s / 1e9 if traffic and dom_s > 0 else None,
                         "measured_frac": traffic / dom_s / 1e9 / HBM_PEAK_GBS if traffic and dom_s > 0 else None,
                         "traffic_source": traffic_src,

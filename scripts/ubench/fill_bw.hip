@@ -13,14 +13,15 @@ __global__ void k_contig(float* T, size_t n4)
         reinterpret_cast<f4*>(T)[i] = v;
 }
 // item layout [tile (cols/8)][row][8] float2; grid = (rows, items); 128 threads x 16 columns each (stride 128)
-__global__ void k_tiles(float* T, int rows, int cols)
+__global__ void k_tiles(float* T, int rows, int cols, int trows = 0)
 {
-    f2* item = reinterpret_cast<f2*>(T) + (size_t)blockIdx.y * rows * cols;
+    if (trows == 0) trows = rows;                                // row stride of a tile (padding experiment)
+    f2* item = reinterpret_cast<f2*>(T) + (size_t)blockIdx.y * trows * cols;
     const int row = blockIdx.x;
     f2 v = {1.f, 2.f};
     for (int m = 0; m < cols / 128; ++m) {
         const int q = threadIdx.x + 128 * m;
-        item[((size_t)(q >> 3) * rows + row) * 8 + (q & 7)] = v;
+        item[((size_t)(q >> 3) * trows + row) * 8 + (q & 7)] = v;
     }
 }
 template <typename F> static double time_ms(F f, int reps)
@@ -41,6 +42,15 @@ int main()
         double c = time_ms([&] { k_tiles<<<dim3(rows, items), 128>>>(T, rows, cols); }, 20);
         printf("%3d items = %7.1f MB rewritten 20x:  contiguous %.2f TB/s   64-B granules (T tiles) %.2f TB/s\n",
                items, bytes / 1e6, bytes / a / 1e9, bytes / c / 1e9);
+    }
+    // tile row stride padding: does the 65,600-byte tile stride of 1025 rows pile the 8 granules of a store instruction
+    // (and the rows of neighbouring workgroups) onto a few memory channels?
+    for (int items : {12, 32}) {
+        for (int trows : {1025, 1026, 1028, 1032, 1040, 1056, 1088, 1152}) {
+            double c = time_ms([&] { k_tiles<<<dim3(rows, items), 128>>>(T, rows, cols, trows); }, 20);
+            printf("%2d items, tile stride %4d rows (%6d B, mod 4096 = %4d): %.2f TB/s\n", items, trows, trows * 64,
+                   (trows * 64) % 4096, item * items / c / 1e9);
+        }
     }
     return 0;
 }

@@ -501,7 +501,8 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
     const bool w64_ok = (pn * 2 == N) && ((N == 512 && rect_ok) || N == 1024 || N == 2048 || N == 4096 ||
                                           (N == 8192 && kn.w64_8192));   // w64_8192 defaults to 1
     // N = pn (the coarse-grid transform, and pixel sizes that give N = pn): full-output variants of the same kernels
-    const bool full_ok = (pn == N) && (N == 1024 || N == 2048 || N == 4096 || (N == 512 && (kn.tile <= 0 || kn.tile == 8)));
+    const bool full_ok = (pn == N) && (N == 1024 || N == 2048 || N == 4096 ||
+                                       ((N == 512 || N == 256) && (kn.tile <= 0 || kn.tile == 8)));
     const bool w64_shape = ((w64_ok && variant == 1) || (full_ok && variant == 0)) && kn.w64;
     // T tile width.  The x-pass's T stores are bound by the memory system's rate for partial-line writes: measured
     // (scripts/ubench/write_bw.hip) 2.2 TB/s for 32-byte granules (4-column tiles), 3.4 TB/s for 64-byte granules
@@ -510,9 +511,10 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
     if (kn.tile <= 0 && w64_shape && !kn.w64x) set_tile(g, h, 8);
     const int tc = 1 << g.tcl;
     // k_ypass_rect: 4096 / N adjacent columns per wave (they must fit one T tile)
-    const bool rect = (variant == 0 ? N <= 2048 : rect_ok && N <= 2048) && (4096 / N) <= tc;
+    const bool rect = (variant == 0 ? N <= 2048 : rect_ok && N <= 2048) && ((4096 / N) <= tc || (N == 256 && tc == 8));
     g.rect_off = rect ? 0 : 1;
-    const bool wave_y = w64_shape && (g.tcl == 2 || g.tcl == 3) && (N != 512 || rect) && (variant == 1 || rect || N == 4096);
+    const bool wave_y = w64_shape && (g.tcl == 2 || g.tcl == 3) && ((N != 512 && N != 256) || rect) &&
+                        (variant == 1 || rect || N == 4096);
 
     // y-pass groups: the grid is (column blocks) x (planes in flight) x G workgroups; pick the smallest group
     // count that makes it a whole number of full-occupancy rounds (256 CUs x workgroups per CU).
@@ -738,8 +740,12 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     AbbePlan pc_plan;
     const SizeOps* ops_c = nullptr;
     EdgeGeom eg;
-    bool coarse = kn.coarse && N == 2 * pn && pp.variant == 1 && !pp.general && pl[13] == 0 &&
-                  (pn == 512 || pn == 1024 || pn == 2048 || pn == 4096);
+    // The reconstruction is a fixed cost per call and plane (about ten small launches: 0.3 ms at 256^2 .. 1.5 ms at
+    // 4096^2), so short source lists stay on the direct path: break-even measured at S = 14,000 (256^2), 1,200
+    // (512^2), < 500 (1024^2), about 100 (2048^2, 4096^2); scripts/total_time.py.  LITHO_ABBE_COARSE = 2 ignores S.
+    const int64_t s_min = pn == 256 ? 16384 : pn == 512 ? 1536 : pn == 1024 ? 384 : 128;
+    bool coarse = kn.coarse && (kn.coarse >= 2 || S >= s_min) && N == 2 * pn && pp.variant == 1 && !pp.general &&
+                  pl[13] == 0 && (pn == 256 || pn == 512 || pn == 1024 || pn == 2048 || pn == 4096);
     if (coarse) {
         eg.pn = pn; eg.c = pn / 2; eg.h = pn / 4;
         eg.lo[0] = pl[10] >= pl[9] ? pl[9] : 0;   eg.len[0] = pl[10] >= pl[9] ? pl[10] - pl[9] + 1 : 0;

@@ -887,7 +887,7 @@ struct SizeImpl {
     static hipError_t ypass_w64(const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb, int planes,
                                 int G, int gstride, hipStream_t st)
     {
-        if constexpr (LOG2N >= 9 && LOG2N <= 13) return launch_ypass_wave<LOG2N>(T, slab, tw, g, nb, planes, G, gstride, st);
+        if constexpr (LOG2N >= 8 && LOG2N <= 13) return launch_ypass_wave<LOG2N>(T, slab, tw, g, nb, planes, G, gstride, st);
         else return hipErrorNotSupported;
     }
     static hipError_t ypass_field(int sign, const float2* T, float2* field, const float2* tw, const PassGeom& g,

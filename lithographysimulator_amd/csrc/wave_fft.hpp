@@ -194,8 +194,8 @@ struct WaveSq {
     }
 
     // ------------------------------------------------------------------------------------------------
-    // NL = 2, 4 or 8 lines of N = S*S/NL points per wave, rectangular split N = S lanes x H slots (H = S / NL;
-    // N = 2048, 1024, 512 for S = 64):
+    // NL = 2, 4, 8 or 16 lines of N = S*S/NL points per wave, rectangular split N = S lanes x H slots (H = S / NL;
+    // N = 2048, 1024, 512, 256 for S = 64):
     //   X[m + H k2] = sum_l wS^(l k2) [ w_N^(l m) sum_j x[l + S j] w_H^(j m) ],   l < S, j, m < H, k2 < S.
     // Slots [line*H, line*H + H) hold line `line` (sample l + S j in slot line*H + j).  Pass A = NL independent
     // H-point DIFs over the slots; the S x S transpose is the square kernel's: column c = line*H + m goes to lane c,
@@ -206,8 +206,8 @@ struct WaveSq {
     template <int NL>
     __device__ static __forceinline__ void run_rect(float2 (&x)[S], const LaneTwiddles& tw, float* lds, int lane)
     {
-        static_assert(LS == 6 && (NL == 2 || NL == 4 || NL == 8), "rectangular multi-line transform: S = 64");
-        constexpr int H = S / NL, LH = LS - (NL == 2 ? 1 : NL == 4 ? 2 : 3);
+        static_assert(LS == 6 && (NL == 2 || NL == 4 || NL == 8 || NL == 16), "rectangular multi-line transform: S = 64");
+        constexpr int H = S / NL, LH = LS - (NL == 2 ? 1 : NL == 4 ? 2 : NL == 8 ? 3 : 4);
         static_for<0, NL>([&](auto q_) { dif_network<LH, decltype(q_)::value * H, S>(x); });   // slot line*H + brev_LH(m) = Y_line[l, m]
         auto slot_of = [](int c) constexpr { return (c / H) * H + brev_bits(c % H, LH); };
         static_for<0, S>([&](auto c_) {

@@ -283,14 +283,17 @@ __global__ __launch_bounds__(256, 2) void k_ypass_rect(
     const float2* __restrict__ Tbuf, float* __restrict__ slab, const float2* __restrict__ twtab,
     PassGeom g, int nb, int G, int gstride)
 {
-    static_assert(LOG2N >= 9 && LOG2N <= 11, "multi-column-per-wave y-pass: N = 512, 1024, 2048");
+    static_assert(LOG2N >= 8 && LOG2N <= 11, "multi-column-per-wave y-pass: N = 256 (full output only), 512, 1024, 2048");
     static_assert(TC == 4 || TC == 8, "T tiles are 4 or 8 columns wide");
+    static_assert(LOG2N >= 9 || FULL, "N = 256: the coarse-grid transform of 256^2 images");
     using W = WaveSq<6>;
     constexpr int S = 64, N = 1 << LOG2N, NL = (S * S) / N, H = S / NL;
     constexpr int JL = FULL ? H / 4 : H / 8;                 // live rows: |k| <= pn/4 = 64 JL
     constexpr int NACC = FULL ? S : S / 2;                   // kept bins per lane
     auto kept_k2 = [](int i) constexpr { return FULL ? i : (i < S / 4 ? i : S / 2 + i); };
-    static_assert(NL <= TC, "the wave's columns must sit in one T tile");
+    static_assert(NL <= TC || NL == 2 * TC, "the wave's columns sit in one T tile, or in two adjacent ones (N = 256)");
+    constexpr int NT = NL <= TC ? 1 : 2;                     // tiles the wave's columns span
+    constexpr int QT = NL / 2 / NT;                          // 16-byte column pairs per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* smem = reinterpret_cast<float*>(smem_raw);
     const int lane = threadIdx.x & 63;
@@ -315,15 +318,18 @@ __global__ __launch_bounds__(256, 2) void k_ypass_rect(
     auto slot_off = [&](int j) { return vb + (unsigned)(j <= JL ? RB * S * j : RB * S * j - RB * N); };
 
     for (int s = grp; s < nb; s += G) {
-        const __amdgpu_buffer_rsrc_t rT =
-            make_rsrc(Tbuf + (size_t)s * g.t_point + (size_t)(active ? tile : 0) * g.rows * TC, tile_bytes);
+        __amdgpu_buffer_rsrc_t rTs[NT];
+        static_for<0, NT>([&](auto t_) {
+            constexpr int t = decltype(t_)::value;
+            rTs[t] = make_rsrc(Tbuf + (size_t)s * g.t_point + (size_t)(active ? tile + t : 0) * g.rows * TC, tile_bytes);
+        });
         float2 x[S];
         static_for<0, H>([&](auto j_) {
             constexpr int j = decltype(j_)::value;
             static_for<0, NL / 2>([&](auto q_) {
                 constexpr int q = decltype(q_)::value;
                 if constexpr (j <= JL || j >= H - JL) {
-                    const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(rT, slot_off(j) + 16u * q, 0, 0);
+                    const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(rTs[q / QT], slot_off(j) + 16u * (q % QT), 0, 0);
                     x[(2 * q) * H + j] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));          // column qx0 + 2q
                     x[(2 * q + 1) * H + j] = make_float2(__uint_as_float(v.z), __uint_as_float(v.w));      // column qx0 + 2q + 1
                 } else {
@@ -475,9 +481,9 @@ static hipError_t launch_ypass_wave_tc(const float2* T, float* slab, const float
             hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, 4>(g.pn), planes * G), dim3(256), ldsf, st, T, slab, tw, g, nb, G,
                                gstride);
             return hipGetLastError();
-        } else if constexpr (LOG2N >= 9 && LOG2N <= 11) {
+        } else if constexpr (LOG2N >= 8 && LOG2N <= 11) {
             constexpr int NL = 4096 >> LOG2N;
-            if constexpr (NL <= TC) {
+            if constexpr (NL <= TC || NL == 2 * TC) {
                 static LdsOnce once;
                 auto kern = k_ypass_rect<LOG2N, TC, true>;
                 hipError_t e = set_lds(once, kern, lds4);

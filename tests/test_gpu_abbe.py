@@ -33,6 +33,16 @@ def O():
     return abbe_oracle
 
 
+@pytest.fixture(params=["auto", "coarse"])
+def coarse_mode(request, monkeypatch):
+    """The library picks the coarse-grid path only for source lists long enough to repay its once-per-image
+    reconstruction; the golden-vector tests at the BASELINE sizes use a handful of points, so they run twice: as a
+    caller gets it ("auto": the direct path here) and with the coarse-grid path forced (LITHO_ABBE_COARSE=2)."""
+    if request.param == "coarse":
+        monkeypatch.setenv("LITHO_ABBE_COARSE", "2")
+    return request.param
+
+
 # ------------------------------------------------------------------ single-point fields (G4)
 @pytest.mark.parametrize("tag", ["demo64", "bern256", "bern64_Neqpn", "bern64_N4pn", "bern96"])
 def test_fields_vs_golden(golden, L, dev, tag):
@@ -128,7 +138,7 @@ def test_other_fft_ratios_vs_golden(golden, L, dev, ps):
     assert rel_max(img, ref) < TOL_IMAGE_MAX
 
 
-@pytest.mark.parametrize("pn,ps", [(512, 48), (512, 10), (1024, 48), (256, 10), (2048, 48)])
+@pytest.mark.parametrize("pn,ps", [(512, 48), (512, 10), (1024, 48), (256, 10), (256, 48), (2048, 48)])
 def test_other_fft_ratios_mid_size_vs_oracle(L, dev, pn, ps):
     """N = pn (pixelSize 48: the RL = 0 pruned kernels, 9 live input slots) and N = 4 pn (pixelSize 10: RL = 2) at
     sizes where a line spans whole workgroups, against the CPU oracle's op chain and its post-process."""
@@ -204,7 +214,7 @@ def test_general_and_pruned_modes_agree(golden, L, dev, monkeypatch):
 @pytest.mark.parametrize("pn,K,skind,ab", [(1024, 16, "annular", [0, 0, 0, 0, 100]),
                                            (2048, 8, "quasar", DEMO_AB),
                                            (4096, 4, "annular", [0, 0, 0, 0, 100])])
-def test_subsampled_baseline_sizes_vs_golden(golden, L, dev, pn, K, skind, ab):
+def test_subsampled_baseline_sizes_vs_golden(golden, L, dev, pn, K, skind, ab, coarse_mode):
     """BASELINE configs 2/3/4 geometry with K source points strided through the real list."""
     from lithographysimulator_amd.synthetic import bernoulli_mask
     g = golden("g5_images.npz")
@@ -219,6 +229,8 @@ def test_subsampled_baseline_sizes_vs_golden(golden, L, dev, pn, K, skind, ab):
     pf = L.Pupil(pn, WL, NA, f16(ab), dev).generatePupilFunction()
     eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
     raw = L.abbeIntensity(mft, pf, L.sourceShifts(bm, pn), N).cpu()
+    from lithographysimulator_amd import _native as nat
+    assert nat.last_plan()["coarse_grid"] == (1 if coarse_mode == "coarse" else 0)     # K points: below the auto threshold
     assert rel_max(crop_center(raw), g[f"sub{pn}_raw_crop"]) < TOL_IMAGE_MAX
     assert np.allclose(raw.double().sum(1).numpy(), g[f"sub{pn}_raw_rowsum"], rtol=2e-5)
     assert np.allclose(raw.double().sum(0).numpy(), g[f"sub{pn}_raw_colsum"], rtol=2e-5)
@@ -231,7 +243,7 @@ def test_subsampled_baseline_sizes_vs_golden(golden, L, dev, pn, K, skind, ab):
 
 @pytest.mark.parametrize("pn,K,skind,ab", [(1024, 6, "annular", [0, 0, 0, 0, 100]), (2048, 3, "quasar", DEMO_AB),
                                            (4096, 1, "annular", [0, 0, 0, 0, 100])])
-def test_whole_image_vs_oracle_at_baseline_sizes(L, dev, pn, K, skind, ab):
+def test_whole_image_vs_oracle_at_baseline_sizes(L, dev, pn, K, skind, ab, coarse_mode):
     """The golden fixtures at 1024^2 .. 4096^2 hold a centre crop and the row / column sums (size limits).  Here EVERY
     pixel of the raw intensity and of the post-processed image is compared with the CPU oracle's op chain (itself
     pinned against those goldens in the CPU suite) for a few source points spread over the real list."""
@@ -256,7 +268,7 @@ def test_whole_image_vs_oracle_at_baseline_sizes(L, dev, pn, K, skind, ab):
 
 
 @pytest.mark.parametrize("pn,ab", [(1024, [0, 0, 0, 0, 100]), (2048, DEMO_AB), (1024, PUPIL15), (2048, None),
-                                   (512, DEMO_AB), (4096, [0, 0, 0, 0, 100])])
+                                   (512, DEMO_AB), (4096, [0, 0, 0, 0, 100]), (256, DEMO_AB), (256, None)])
 def test_coarse_grid_path_agrees_with_direct_path(L, dev, monkeypatch, pn, ab):
     """Default at 1024^2 / 2048^2 (N = 2 pn): the source-point loop runs pn-point transforms on the coarse grid q = 2 v
     and the fine image is reconstructed once per plane (band-limited interpolation + exact Nyquist-line correction).
@@ -264,12 +276,13 @@ def test_coarse_grid_path_agrees_with_direct_path(L, dev, monkeypatch, pn, ab):
     an accumulate-into-live-buffer call; ideal pupil (real, box edges at their smallest) and a 15-term pupil."""
     from lithographysimulator_amd import _native as nat
     from lithographysimulator_amd.synthetic import bernoulli_mask
+    monkeypatch.setenv("LITHO_ABBE_COARSE", "2")                 # short source lists: force the path under test
     mask = L.Mask(bernoulli_mask(pn), PS, dev)
     mft = mask.fraunhofer(WL, True)
     eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
     pf = L.Pupil(pn, WL, NA, None if ab is None else f16(ab), dev).generatePupilFunction()
     sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateQuasar(4, -math.pi / 8), pn)
-    K = {512: 300, 1024: 150, 2048: 40, 4096: 12}[pn]
+    K = {256: 900, 512: 300, 1024: 150, 2048: 40, 4096: 12}[pn]
     sel = sh[(torch.arange(K, device=dev) * sh.shape[0]) // K]
     coarse = L.abbeIntensity(mft, pf, sel, N)
     assert nat.last_plan()["coarse_grid"] == 1 and nat.last_plan()["variant"] == 1
@@ -298,6 +311,7 @@ def test_coarse_grid_xpass_kernels_agree(L, dev, monkeypatch, pn):
     stores): both must give the same image, ragged last row group and several batches included."""
     from lithographysimulator_amd import _native as nat
     from lithographysimulator_amd.synthetic import bernoulli_mask
+    monkeypatch.setenv("LITHO_ABBE_COARSE", "2")
     mask = L.Mask(bernoulli_mask(pn), PS, dev)
     mft = mask.fraunhofer(WL, True)
     eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
@@ -342,7 +356,7 @@ def test_through_focus_demo_planes(golden, L, dev):
         assert rel_max(img, g["stack64_final"][k]) < TOL_IMAGE_MAX
 
 
-def test_config5_stack_at_size_vs_golden(golden, L, dev):
+def test_config5_stack_at_size_vs_golden(golden, L, dev, coarse_mode):
     """BASELINE config 5 AT ITS SIZE: 2048^2 x 32 through-focus planes (d_k = -310 + 20 k nm), K = 3 strided quasar
     points, against the reference's own loop over Pupil(...) + abbeImage(...) (golden g9).  The stack goes through
     the plane-fused x-pass (mask-spectrum window gathered once per source point for the planes in flight)."""
@@ -570,13 +584,18 @@ def test_properties_2048(L, dev):
 
 # ------------------------------------------------------------------ kernel variants must agree with each other
 def _with_env(monkeypatch, L, env, fn):
+    import os
+    old = {k: os.environ.get(k) for k in env}
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     try:
         return fn()
     finally:
-        for k in env:
-            monkeypatch.delenv(k, raising=False)
+        for k, v in old.items():
+            if v is None:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, v)
 
 
 def test_wave_per_line_and_radix16_ypass_agree_2048(L, dev, monkeypatch):

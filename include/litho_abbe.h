@@ -86,7 +86,12 @@ int litho_abbe_workspace_bytes(int pn, int N, size_t *bytes_host);
  * stack sharing maskFT and the source list); shifts int32 [S,2] = (dy,dx) =
  * (row - pn/2, col - pn/2); out fp32 [planes,pn,pn], accumulated into (the caller zeroes
  * it, and all-reduces it across GPUs when the source list is sharded).
- * Reads back 36 bytes once (pupil support box, shift extents, count) to plan the launch. */
+ * Reads back 56 bytes once (pupil support box, its edge supports, shift extents, count) to plan the launch.
+ * How the sum is evaluated is the library's business: for N = 2 pn, pn = 256 .. 4096 and a source list long
+ * enough to repay it, the loop runs pn-point transforms on the grid q = 2 v and the fine image is reconstructed
+ * once per call and plane; same result to rounding.  Environment, read once per call:
+ * LITHO_ABBE_COARSE = 0 (never) / 1 (default: by source count) / 2 (whenever eligible); the other LITHO_ABBE_*
+ * variables select kernel variants for parity tests and tuning. */
 int litho_abbe_accumulate(const void *maskFT, const void *pupil, int planes,
                           const int32_t *shifts, int64_t S, int pn, int N, float *out,
                           void *workspace, size_t workspace_bytes, void *stream);

@@ -1,4 +1,5 @@
 import math, os, sys, torch
+import os as _os; _os.environ.setdefault("LITHO_ABBE_COARSE", "2")   # timing probes use short source lists: do not let the S threshold pick the direct path silently
 sys.path.insert(0, "/root/repo")
 import lithographysimulator_amd as L
 from lithographysimulator_amd import _native as nat

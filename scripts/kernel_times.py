@@ -1,5 +1,6 @@
 """Per-kernel HIP-event times (x-pass / y-pass) for the libs given: python scripts/kernel_times.py pn K lib1,lib2"""
 import math, os, subprocess, sys
+import os as _os; _os.environ.setdefault("LITHO_ABBE_COARSE", "2")   # timing probes use short source lists: do not let the S threshold pick the direct path silently
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if sys.argv[1] == "--child":
     import torch

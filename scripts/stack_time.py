@@ -1,6 +1,7 @@
 """Device-time probe of a through-focus stack (config-5 geometry): python scripts/stack_time.py pn planes K
 Prints us per T item (source point x plane) for the x-pass and the y-pass; knobs via LITHO_ABBE_* env."""
 import math
+import os as _os; _os.environ.setdefault("LITHO_ABBE_COARSE", "2")   # timing probes use short source lists: do not let the S threshold pick the direct path silently
 import os
 import sys
 

@@ -1,6 +1,7 @@
 """Wall-clock (HIP events around the call) of one abbeIntensity over K consecutive source points:
     python scripts/total_time.py pn K [planes]        -> us per source point (and plane), best of 3"""
 import math, os, sys, torch
+import os as _os; _os.environ.setdefault("LITHO_ABBE_COARSE", "2")   # timing probes use short source lists: do not let the S threshold pick the direct path silently
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lithographysimulator_amd as L
 from lithographysimulator_amd import _native as nat

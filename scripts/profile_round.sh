@@ -16,4 +16,5 @@ python3 bench.py --workload cfg5 --steps 1 --warmup 0 --no-cpu-baseline > $O/ben
 [ -n "$SKIP_PMC" ] || bash scripts/pmc_traffic.sh $R cfg3 504 cfg2 2016 cfg4 64 cfg5 120 cfg1 3233
 # keep the summaries small: the raw per-dispatch CSVs stay in gpurun_out
 find $O -name "*_agent_info.csv" -delete
+find $O/stats -name "*_kernel_trace.csv" -delete        # 80k rows per image: the stats csv is the summary that gets committed
 ls -la $O

@@ -554,7 +554,12 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
     if (items_ws < 1) return LITHO_E_WORKSPACE;
     int64_t items = items_ws;
     int64_t items_cache = (int64_t)(((size_t)208 << 20) / item_bytes);
-    if (items_cache < 8) items_cache = 8;
+    // 4096^2 (67 MB per item): not even 8 items fit the cache, T round-trips HBM whatever the batch -- then the batch
+    // is as long as the workspace allows (15 items: fewer accumulator flushes in the y-pass) and an x-pass workgroup
+    // walks the WHOLE batch for its row (one prologue per row).  us per source point, coarse-grid path, alternating
+    // A/B: 8 items x chunks of 4 49.9 / 49.8; 12 x 6 47.9; 12 x 12 45.6; 15 x 5 47.5; 15 x 15 45.3 / 45.2.
+    const bool beyond_cache = items_cache < 8;
+    if (beyond_cache) items_cache = 16;
     if (items > items_cache) items = items_cache;
     if (PC > items_ws) PC = (int)items_ws;
     int G = Gtot / PC;                                         // groups per plane
@@ -579,6 +584,7 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
         xchunk = want;
         if (want == 4) for (int cand : {4, 5, 3, 6, 2}) if (bs % cand == 0) { xchunk = cand; break; }
         if (want == 2) for (int cand : {2, 3, 1}) if (bs % cand == 0) { xchunk = cand; break; }
+        if (beyond_cache && PC == 1) xchunk = (int)bs;         // see above
     }
 
     // N = 8192 = 2 pn: each row as two 4096-point transforms (k_xpass_split) instead of the 8192-point engine

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void k_ypass_rect(
     PassGeom g, int nb, int G, int gstride)
 {
     static_assert(LOG2N >= 8 && LOG2N <= 11, "multi-column-per-wave y-pass: N = 256 (full output only), 512, 1024, 2048");
-    static_assert(TC == 4 || TC == 8, "T tiles are 4 or 8 columns wide");
+    static_assert(TC == 2 || TC == 4 || TC == 8, "T tiles are 2, 4 or 8 columns wide");
     static_assert(LOG2N >= 9 || FULL, "N = 256: the coarse-grid transform of 256^2 images");
     using W = WaveSq<6>;
     constexpr int S = 64, N = 1 << LOG2N, NL = (S * S) / N, H = S / NL;

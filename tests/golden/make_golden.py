@@ -388,9 +388,82 @@ def g10_contiguous_shards():
     save("g10_contiguous_shards.npz", **out)
 
 
+def full_image_with_raw(mk, mft, pf, bm):
+    """ONE run of the reference's own abbeImage (imageformation.py:47-77) that also yields the raw accumulated
+    intensity: the tensor the reference hands to F.interpolate at :71 is abs(image), i.e. the loop's sum."""
+    import torch.nn.functional as F
+    captured = {}
+    orig = F.interpolate
+
+    def spy(inp, *a, **k):
+        captured["raw"] = inp.squeeze(0).squeeze(0).clone()
+        return orig(inp, *a, **k)
+
+    F.interpolate = spy
+    try:
+        final = ref_if.abbeImage(mk, mft, pf, bm, PS, mk.deltaK, WL, True, CPU)
+    finally:
+        F.interpolate = orig
+    return final, captured["raw"]
+
+
+def g11_config2_full():
+    """BASELINE config 2 IN FULL, by the reference itself: 1024^2 bernoulli mask, annular 0.4-0.8 (S = 98,832),
+    defocus-only pupil [0,0,0,0,100] -- the reference's sequential fp32 loop over every source point (about two hours
+    on this container's CPUs).  Stored: centre crops, a stride-8 sample of every region, fp64 row / column sums, max
+    and sum of the raw accumulated intensity and of the final image."""
+    print("G11 config 2 in full (reference loop over 98,832 source points)")
+    import time
+    pn = 1024
+    out = {}
+    mk = quiet(ref_mask.Mask, bernoulli_mask(pn), PS, CPU)
+    mft = mk.fraunhofer(WL, True)
+    bm = source("annular", pn, 0.4, 0.8)
+    pf = pupil_fn(pn, [0, 0, 0, 0, 100])
+    out["S"] = np.int64(bm.sum())
+    t0 = time.time()
+    final, raw = full_image_with_raw(mk, mft, pf, bm)
+    out["reference_seconds"] = np.float64(time.time() - t0)
+    out["reference_threads"] = np.int64(torch.get_num_threads())
+    for tag, img in (("final", final), ("raw", raw)):
+        crop_stats(f"cfg2full_{tag}", img, out)
+        out[f"cfg2full_{tag}_stride8"] = img[::8, ::8].contiguous()
+    print(f"   S={int(out['S'])}  {float(out['reference_seconds']):.0f} s  final sum {float(final.double().sum()):.7e} "
+          f"max {float(final.max()):.7e}", flush=True)
+    save("g11_config2_full.npz", **out)
+
+
+def g12_shard4096():
+    """A consecutive 64-point shard at 4096^2 (BASELINE config 4: annular 0.4-0.8, defocus pupil), points
+    [800000, 800064) of the row-major list, by the reference's own abbeImage: raw intensity and the 4094^2 final
+    image (quirk Q5) over a run that spans several launch batches of the engine."""
+    print("G12 consecutive shard at 4096^2")
+    pn, lo, n = 4096, 800000, 64
+    out = {}
+    mk = quiet(ref_mask.Mask, bernoulli_mask(pn), PS, CPU)
+    mft = mk.fraunhofer(WL, True)
+    full = source("annular", pn, 0.4, 0.8)
+    pts = torch.argwhere(full)
+    bm = torch.zeros_like(full)
+    sel = pts[lo:lo + n]
+    bm[sel[:, 0], sel[:, 1]] = 1
+    pf = pupil_fn(pn, [0, 0, 0, 0, 100])
+    final, raw = full_image_with_raw(mk, mft, pf, bm)
+    for tag, img in (("final", final), ("raw", raw)):
+        crop_stats(f"cfg4shard_{tag}", img, out)
+        out[f"cfg4shard_{tag}_stride32"] = img[::32, ::32].contiguous()
+    out["cfg4shard_range"] = np.array([lo, lo + n, pts.shape[0]], dtype=np.int64)
+    out["cfg4shard_first_last_shift"] = shifts_of(bm, pn)[[0, -1]]
+    print(f"   points [{lo},{lo + n}) of {pts.shape[0]}  final shape {tuple(final.shape)}  sum={float(final.double().sum()):.7e}", flush=True)
+    save("g12_shard4096.npz", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if os.environ.get("LITHO_GOLDEN_THREADS"):
+        torch.set_num_threads(int(os.environ["LITHO_GOLDEN_THREADS"]))
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g10"]
     for g in which:
         {"g1": g1_sources, "g2": g2_pupils, "g3": g3_mask_spectra, "g4": g4_fields,
-         "g5": g5_images, "g6": g6_through_focus, "g8": g8_large_pupils, "g9": g9_config5_stack, "g10": g10_contiguous_shards}[g]()
+         "g5": g5_images, "g6": g6_through_focus, "g8": g8_large_pupils, "g9": g9_config5_stack, "g10": g10_contiguous_shards,
+         "g11": g11_config2_full, "g12": g12_shard4096}[g]()

@@ -2,6 +2,7 @@
 """Headline benchmark: Abbe source-points x image-pixels per second on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg1..cfg5] [--shard i/n] [--points K]
+                    [--no-cpu-baseline] [--no-extra]
 
 One "step" = one complete abbeImage call (source-list compaction, Abbe accumulation over every source point --
 and every through-focus plane -- of the configuration, all-reduce when N > 1, post-process) on synthetic inputs
@@ -15,16 +16,22 @@ environment.  Started as a plain process with --gpus N > 1, this file starts the
 processes (before anything in the parent touches the GPU), waits for them and relays rank 0's JSON line.
 
 Rank 0 prints one JSON line (contract in the task statement) carrying
-  roofline     the dominant kernel against the bound the counters show: VALU issue.  achieved = nominal FFT flops
-               (5 N log2 N per transformed line) of one launch / its HIP-event-timed duration, peak = 157.3
-               TFLOP/s fp32 vector.  The HBM view sits beside it: `traffic` = PMC-measured memory-side bytes per
-               launch of THIS workload (profiles/traffic.json, made by scripts/pmc_traffic.sh from rocprofv3 --pmc
-               passes over this very command), `hbm.measured_frac` = traffic / time / 8 TB/s, and
-               `hbm.effective_40B` = the SURVEY 8d 40-byte model over kernel time, labelled effective because
-               most of those bytes are never moved (pupil-box pruning, on-chip accumulators, cache-resident M/P);
-  cpu_baseline (N = 1) the oracle's torch-CPU op chain, i.e. a port of the reference loop, on a bounded sample.
+  roofline        the dominant kernel (name reported by the library, litho_abbe_last_kernels) against the bound the
+                  counters and microbenchmarks show: fp32 VALU issue.  achieved = nominal FFT flops (5 N log2 N per
+                  transformed line) of one launch / its HIP-event-timed duration, peak = 157.3 TFLOP/s fp32 vector.
+                  Beside it, as top-level keys: `traffic` = PMC-measured L2 memory-side bytes per launch of THIS
+                  workload (profiles/traffic.json: rocprofv3 --pmc passes over this very command; Infinity-Cache hits
+                  INCLUDED, so this is fabric traffic, not HBM traffic), `fabric_frac` = traffic / time / 8 TB/s,
+                  `effective_40B_over_peak` = the SURVEY 8d 40-byte model over kernel time / 8 TB/s (labelled
+                  effective: most of those bytes are never moved), `copy_ceiling_GBs` = this box's own 1 GiB copy rate;
+  cpu_baseline    (N = 1) the oracle's torch-CPU op chain, i.e. a port of the reference loop, on a bounded sample, with
+                  the GPU-vs-CPU parity of that sample taken on the SAME evaluation path the timed step ran;
+  extra_workloads (default run only) one or two timed steps each of config 1, config 2, one rank's shard of config 4
+                  and the config 5 stack, so that every BASELINE configuration has a driver-observed number;
+  ranks           (N > 1) per-rank step time, compute time and all-reduce time of one instrumented step.
 """
 import argparse
+import contextlib
 import json
 import math
 import os
@@ -68,6 +75,8 @@ def parse_args():
     ap.add_argument("--points", type=int, default=0,
                     help="profiling aid: only the first K consecutive source points (the JSON line is then marked partial)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the extra_workloads leg (configs 1, 2, 4-shard, 5) of the default single-GPU run")
     return ap.parse_args()
 
 
@@ -105,6 +114,133 @@ def spawn_ranks(args):
     sys.exit(worst)
 
 
+class Workload:
+    """Synthetic inputs of one BASELINE configuration, resident on the device."""
+
+    def __init__(self, name, dev):
+        import torch
+        import lithographysimulator_amd as L
+        from lithographysimulator_amd.synthetic import bernoulli_mask
+        self.name = name
+        self.pn, skind, ab, self.planes, self.desc = WORKLOADS[name]
+        pn = self.pn
+        with contextlib.redirect_stdout(sys.stderr):         # the object API prints reference-style notices
+            self.mask = L.Mask(bernoulli_mask(pn), PS, dev)
+            self.maskFT = self.mask.fraunhofer(WL, True)
+            self.epsilon, self.N = self.mask.calculateEpsilonN(self.mask.deltaK, PS, WL)
+            if skind == "circ":
+                self.bitmap = L.LightSource(0.0, 0.5, pn, NA, device=dev).generateAnnular()
+            else:
+                ls = L.LightSource(0.4, 0.8, pn, NA, device=dev)
+                self.bitmap = ls.generateAnnular() if skind == "annular" else ls.generateQuasar(4, -math.pi / 8)
+            if self.planes == 1:
+                self.pupil = L.Pupil(pn, WL, NA, None if ab is None else torch.tensor(ab, dtype=torch.float16), dev).generatePupilFunction()
+            else:
+                self.pupil = L.throughFocusPupils(pn, WL, NA, torch.tensor(ab, dtype=torch.float16),
+                                                  [float(d) for d in DEFOCUS_NM[:self.planes]], dev)
+        self.S_full = int(self.bitmap.sum())
+        self.dev = dev
+        torch.cuda.synchronize()
+
+    def step(self, lo=0, hi=None, group=None):
+        """One complete image: the whole source list through abbeImage, or the slice [lo, hi) through the three calls
+        abbeImage makes per rank."""
+        import lithographysimulator_amd as L
+        if hi is None or (lo, hi) == (0, self.S_full):
+            return L.abbeImage(self.mask, self.maskFT, self.pupil, self.bitmap, PS, self.mask.deltaK, WL, True, self.dev, group=group)
+        sh = L.sourceShifts(self.bitmap, self.pn)[lo:hi]
+        return L.postProcess(L.abbeIntensity(self.maskFT, self.pupil, sh, self.N), self.epsilon)
+
+
+def kernel_profile(nat, prof, plan, pn, N):
+    """Per-kernel-class figures of one profiled call (HIP events recorded by the library on the launch stream)."""
+    lines = {"xpass": plan["box_rows"], "ypass": pn}            # lines transformed per T item
+    n_exec = pn if plan.get("coarse_grid") else N                # coarse-grid path: pn-point transforms on the grid q = 2 v
+    line_flops = 5.0 * n_exec * math.log2(n_exec)                # nominal FFT flops of one transformed line
+    kern = {}
+    for k in ("xpass", "ypass"):
+        launches = max(1, prof[f"{k}_launches"])
+        items = prof[f"{k}_points"]                              # T items = source points x planes
+        avg_ms = prof[f"{k}_ms"] / launches
+        per_launch = items / launches
+        flops = line_flops * lines[k] * per_launch
+        algo_bytes = ALGO_BYTES[k] * pn * pn * per_launch
+        kern[k] = {"kernel": prof[f"{k}_kernel"], "avg_launch_ms": avg_ms, "launches": launches, "items_per_launch": per_launch,
+                   "nominal_flops_per_launch": flops,
+                   "achieved_TFLOPs": flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
+                   "algorithmic_bytes_per_launch": algo_bytes,
+                   "effective_GBs": algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
+                   "total_ms": prof[f"{k}_ms"]}
+    return kern, n_exec
+
+
+def measured_ceilings(torch, dev):
+    """Device-copy and device-fill rates of THIS box (1 GiB, beyond the 256 MiB Infinity Cache): what the memory
+    system sustains for plain streams, to put next to the 8 TB/s spec the fractions are quoted against."""
+    try:
+        a = torch.empty(1 << 28, dtype=torch.float32, device=dev); b = torch.empty_like(a)
+        b.copy_(a); a.zero_(); torch.cuda.synchronize()
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        for _ in range(5): b.copy_(a)
+        e1.record()
+        for _ in range(5): a.zero_()
+        e2.record(); torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9      # read + write bytes
+        fill_gbs = 5 * a.numel() * 4 / (e1.elapsed_time(e2) * 1e-3) / 1e9          # write bytes
+        del a, b
+        return copy_gbs, fill_gbs
+    except Exception:
+        return None, None
+
+
+def extra_workload(torch, nat, dev, name, shard=None, steps=1, warm_points=0, profile_points=480):
+    """One or two timed steps of another BASELINE configuration (same fences as the headline), plus a short profiled
+    run for the x-pass / y-pass split."""
+    import lithographysimulator_amd as L
+    w = Workload(name, dev)
+    lo, hi = 0, w.S_full
+    note = None
+    if shard:
+        from lithographysimulator_amd.distributed import shard_bounds
+        lo, hi = shard_bounds(w.S_full, shard[0], shard[1])
+        note = f"shard {shard[0]}/{shard[1]} of the source list (per-rank work of the {shard[1]}-GPU run, no all-reduce)"
+    if warm_points:                                              # allocate the workspace, warm the code objects
+        w.step(lo, min(hi, lo + warm_points))
+    else:
+        w.step(lo, hi)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        image = w.step(lo, hi)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    plan = nat.last_plan()
+    S = hi - lo
+    units = float(S) * w.pn * w.pn * w.planes
+    nat.set_profiling(True)
+    sh = L.sourceShifts(w.bitmap, w.pn)[lo:min(hi, lo + profile_points)]
+    L.abbeIntensity(w.maskFT, w.pupil if w.planes == 1 else w.pupil[:2], sh, w.N)
+    torch.cuda.synchronize()
+    prof = nat.last_profile()
+    kern, n_exec = kernel_profile(nat, prof, nat.last_plan(), w.pn, w.N)
+    nat.set_profiling(False)
+    both = kern["xpass"]["total_ms"] + kern["ypass"]["total_ms"]
+    dom = max(kern, key=lambda k: kern[k]["total_ms"])
+    out = {"workload": f"BASELINE {name}: {w.desc}" + (f" [{note}]" if note else ""), "steps": steps,
+           "ms_per_step": elapsed / steps * 1e3, "value": units * steps / elapsed, "unit": "source-pt*px/s",
+           "source_points": S, "source_points_full": w.S_full, "planes": w.planes, "pn": w.pn, "fft_n": w.N,
+           "executed_fft_n": n_exec, "image_shape": list(image.shape), "plan": plan,
+           "dominant_kernel": kern[dom]["kernel"], "dominant_kernel_time_frac": kern[dom]["total_ms"] / both if both else None,
+           "dominant_kernel_valu_frac": kern[dom]["achieved_TFLOPs"] / VALU_PEAK_TFLOPS,
+           "kernels": {k: {"kernel": v["kernel"], "avg_launch_ms": v["avg_launch_ms"], "items_per_launch": v["items_per_launch"]}
+                       for k, v in kern.items()},
+           "profile_sample": f"first {sh.shape[0]} consecutive source points" + (" x 2 planes" if w.planes > 1 else "")}
+    del w, image
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -133,27 +269,9 @@ def main():
 
     import lithographysimulator_amd as L
     from lithographysimulator_amd import _native as nat
-    from lithographysimulator_amd.synthetic import bernoulli_mask
 
-    import contextlib
-    pn, skind, ab, planes, desc = WORKLOADS[args.workload]
-    _notices = contextlib.redirect_stdout(sys.stderr)      # the object API prints reference-style notices
-    _notices.__enter__()
-    mask = L.Mask(bernoulli_mask(pn), PS, dev)
-    maskFT = mask.fraunhofer(WL, True)
-    epsilon, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
-    if skind == "circ":
-        bitmap = L.LightSource(0.0, 0.5, pn, NA, device=dev).generateAnnular()
-    else:
-        ls = L.LightSource(0.4, 0.8, pn, NA, device=dev)
-        bitmap = ls.generateAnnular() if skind == "annular" else ls.generateQuasar(4, -math.pi / 8)
-    if planes == 1:
-        pupil = L.Pupil(pn, WL, NA, None if ab is None else torch.tensor(ab, dtype=torch.float16), dev).generatePupilFunction()
-    else:
-        pupil = L.throughFocusPupils(pn, WL, NA, torch.tensor(ab, dtype=torch.float16), [float(d) for d in DEFOCUS_NM[:planes]], dev)
-    S_full = int(bitmap.sum())
-    torch.cuda.synchronize()
-    _notices.__exit__(None, None, None)
+    w = Workload(args.workload, dev)
+    pn, planes, N, S_full = w.pn, w.planes, w.N, w.S_full
 
     # ---- what one step processes
     lo, hi, shard_note = 0, S_full, None
@@ -168,13 +286,9 @@ def main():
         hi = min(hi, lo + args.points)
         shard_note = (shard_note + "; " if shard_note else "") + f"PARTIAL: first {hi - lo} consecutive source points only"
     S = hi - lo
-    partial = (lo, hi) != (0, S_full)
 
     def step():
-        if not partial:
-            return L.abbeImage(mask, maskFT, pupil, bitmap, PS, mask.deltaK, WL, True, dev, group=group)
-        sh = L.sourceShifts(bitmap, pn)[lo:hi]              # the three lines abbeImage runs per rank
-        return L.postProcess(L.abbeIntensity(maskFT, pupil, sh, N), epsilon)
+        return w.step(lo, hi, group=group)
 
     def fence():
         torch.cuda.synchronize()
@@ -189,11 +303,44 @@ def main():
     for _ in range(args.steps):
         image = step()
     fence()
-    elapsed = time.perf_counter() - t0
+    elapsed_own = time.perf_counter() - t0
+    elapsed = elapsed_own
+    ranks = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        cdev = dev if backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed_own], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # one more, instrumented step: this rank's compute (its shard of the Abbe sum) and the all-reduce, by events
+        from lithographysimulator_amd.distributed import shard_bounds
+        from lithographysimulator_amd.imageformation import _all_reduce_sum
+        sh_all = L.sourceShifts(w.bitmap, pn)
+        rlo, rhi = shard_bounds(sh_all.shape[0], rank, world)
+        fence()
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        h0 = time.perf_counter()
+        e0.record()
+        part = L.abbeIntensity(w.maskFT, w.pupil, sh_all[rlo:rhi], N)
+        e1.record()
+        torch.cuda.synchronize()
+        h1 = time.perf_counter()
+        _all_reduce_sum(part, group)
+        e2.record()
+        torch.cuda.synchronize()
+        h2 = time.perf_counter()
+        mine = torch.tensor([elapsed_own / args.steps * 1e3, e0.elapsed_time(e1), (h2 - h1) * 1e3, float(rhi - rlo)],
+                            dtype=torch.float64, device=cdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rows = [[float(v) for v in r.cpu()] for r in allr]
+        ranks = {"step_ms": [r[0] for r in rows], "compute_ms": [r[1] for r in rows],
+                 "allreduce_wait_ms": [r[2] for r in rows], "source_points": [int(r[3]) for r in rows],
+                 "step_ms_max": max(r[0] for r in rows), "step_ms_min": min(r[0] for r in rows),
+                 "allreduce_bytes": int(part.numel() * 4),
+                 "note": "step_ms = each rank's own mean over the timed steps; compute_ms (HIP events) and "
+                         "allreduce_wait_ms (host clock from this rank's compute done to its all-reduce done: "
+                         "collective + waiting for the slowest rank) from one extra instrumented step"}
+        del part, sh_all
     ms_per_step = elapsed / args.steps * 1e3
     units = float(S) * pn * pn * planes                          # source-point*pixels per step, whole job
     value = units * args.steps / elapsed
@@ -205,49 +352,8 @@ def main():
     prof = nat.last_profile()
     plan = nat.last_plan()
     nat.set_profiling(False)
-    # measured device-copy and device-fill ceilings of THIS box (1 GiB, beyond the 256 MiB Infinity Cache): what the
-    # memory system sustains for plain streams, to put next to the 8 TB/s spec the fractions are quoted against
-    copy_gbs = fill_gbs = None
-    try:
-        a = torch.empty(1 << 28, dtype=torch.float32, device=dev); b = torch.empty_like(a)
-        b.copy_(a); a.zero_(); torch.cuda.synchronize()
-        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        e0.record()
-        for _ in range(5): b.copy_(a)
-        e1.record()
-        for _ in range(5): a.zero_()
-        e2.record(); torch.cuda.synchronize()
-        copy_gbs = 5 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9      # read + write bytes
-        fill_gbs = 5 * a.numel() * 4 / (e1.elapsed_time(e2) * 1e-3) / 1e9          # write bytes
-        del a, b
-    except Exception:
-        pass
-    lines = {"xpass": plan["box_rows"], "ypass": pn}            # lines transformed per T item
-    n_exec = pn if plan.get("coarse_grid") else N                # coarse-grid path: pn-point transforms on the grid q = 2 v
-    line_flops = 5.0 * n_exec * math.log2(n_exec)                # nominal FFT flops of one transformed line
-    # the kernels' names as rocprofv3 prints them (profiles/*_kernel_stats.csv), from the plan the library reports
-    l2, full = int(math.log2(n_exec)), ", true" if n_exec == pn else ""
-    if prof["ypass_kernel"] == "k_ypass_wave":
-        yname = ("k_ypass_pair<13, 8>" if l2 == 13 else f"k_ypass_wave<12, 8{full}>" if l2 == 12
-                 else f"k_ypass_rect<{l2}, 8{full}>")
-    else:
-        yname = "k_ypass_acc"
-    xname = {1: f"k_xpass_abbe<{l2}, {int(math.log2(n_exec // pn))}, true, 1>", 2: "k_xpass_split<13>",
-             3: f"k_xpass_rect<{l2}{', true' if full else ''}>"}.get(plan.get("fused_xpass"), "k_xpass")
-    kern = {}
-    for k in ("xpass", "ypass"):
-        launches = max(1, prof[f"{k}_launches"])
-        items = prof[f"{k}_points"]                              # T items = source points x planes
-        avg_ms = prof[f"{k}_ms"] / launches
-        per_launch = items / launches
-        flops = line_flops * lines[k] * per_launch
-        algo_bytes = ALGO_BYTES[k] * pn * pn * per_launch
-        kern[k] = {"avg_launch_ms": avg_ms, "launches": launches, "items_per_launch": per_launch,
-                   "nominal_flops_per_launch": flops,
-                   "achieved_TFLOPs": flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
-                   "algorithmic_bytes_per_launch": algo_bytes,
-                   "effective_GBs": algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
-                   "total_ms": prof[f"{k}_ms"]}
+    copy_gbs, fill_gbs = measured_ceilings(torch, dev)
+    kern, n_exec = kernel_profile(nat, prof, plan, pn, N)
     dom = max(kern, key=lambda k: kern[k]["total_ms"])
     traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")       # PMC-derived memory-side bytes (rocprofv3 --pmc)
@@ -264,40 +370,42 @@ def main():
     both_flops = sum(kern[k]["nominal_flops_per_launch"] * kern[k]["launches"] for k in kern)
     eff40 = 40.0 * pn * pn * prof["ypass_points"] / (both_ms * 1e-3) / 1e9 if both_ms else 0.0
     dom_s = kern[dom]["avg_launch_ms"] * 1e-3
-    roofline = {"bound": "valu", "kernel": yname if dom == "ypass" else xname,
+    fabric_gbs = traffic / dom_s / 1e9 if traffic and dom_s > 0 else None
+    roofline = {"bound": "valu", "kernel": kern[dom]["kernel"],
                 "achieved": kern[dom]["achieved_TFLOPs"], "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": kern[dom]["achieved_TFLOPs"] / VALU_PEAK_TFLOPS, "traffic": traffic,
                 "avg_launch_ms": kern[dom]["avg_launch_ms"],
                 "nominal_flops_per_launch": kern[dom]["nominal_flops_per_launch"],
-                "note": "measured limiter is fp32 VALU issue (PMC: profiles/); achieved = nominal 5*N*log2(N) flops per "
-                        "transformed line (pruned transforms execute fewer) / HIP-event launch time; traffic = PMC "
-                        "memory-side bytes per launch of this workload",
+                "kernel_time_frac": kern[dom]["total_ms"] / both_ms if both_ms else None,
+                "fabric_GBs": fabric_gbs, "fabric_frac": fabric_gbs / HBM_PEAK_GBS if fabric_gbs else None,
+                "effective_40B_GBs": eff40, "effective_40B_over_peak": eff40 / HBM_PEAK_GBS,
+                "copy_ceiling_GBs": copy_gbs, "fill_ceiling_GBs": fill_gbs, "hbm_peak_GBs": HBM_PEAK_GBS,
+                "note": "bound: fp32 VALU issue (profiles/r03_*: the kernel's instruction stream issues at 1.9 ns per "
+                        "instruction per SIMD against a measured 1.0-1.26 ns floor at two waves per SIMD; packed fp32 "
+                        "gives no extra rate on gfx950).  achieved = nominal 5*N*log2(N) flops per transformed line "
+                        "(pruned transforms execute fewer) / HIP-event launch time.  traffic / fabric_* = PMC bytes the "
+                        "L2 exchanged with the fabric per launch of this workload, Infinity-Cache hits INCLUDED (T is kept "
+                        "inside that cache on purpose): an upper bound on HBM traffic, not HBM traffic.  effective_40B_* "
+                        "divide the SURVEY 8d byte MODEL by x-pass + y-pass kernel time: most of those bytes are never "
+                        "moved, so it exceeds the peak and is not a roofline fraction",
+                "traffic_source": traffic_src,
                 "pipeline": {"achieved": both_flops / (both_ms * 1e-3) / 1e12 if both_ms else 0.0,
                              "frac": both_flops / (both_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS if both_ms else 0.0,
                              "note": "x-pass + y-pass nominal flops over their summed kernel time"},
-                "hbm": {"peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "measured_copy_ceiling": copy_gbs, "measured_fill_ceiling": fill_gbs,
-                        "measured": traffic / dom_s / 1e9 if traffic and dom_s > 0 else None,
-                        "measured_frac": traffic / dom_s / 1e9 / HBM_PEAK_GBS if traffic and dom_s > 0 else None,
-                        "traffic_source": traffic_src,
-                        "algorithmic_bytes_per_launch": kern[dom]["algorithmic_bytes_per_launch"],
-                        "effective_kernel": kern[dom]["effective_GBs"],
-                        "effective_40B": eff40, "effective_40B_over_peak": eff40 / HBM_PEAK_GBS,
-                        "note": "effective_* divide the SURVEY 8d byte MODEL (16 B/unit y-pass, 24 B/unit x-pass, 40 B/unit "
-                                "pipeline) by kernel time; they exceed what HBM could stream because most of those "
-                                "bytes are never moved -- not a roofline fraction"},
                 "kernels": kern}
 
     out = {"metric": "Abbe source-points x image-pixels per second", "value": value, "unit": "source-pt*px/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic",
-           "config": {"workload": f"BASELINE {args.workload}: {desc}" + (f" [{shard_note}]" if shard_note else ""),
+           "config": {"workload": f"BASELINE {args.workload}: {w.desc}" + (f" [{shard_note}]" if shard_note else ""),
                       "pn": pn, "fft_n": N, "executed_fft_n": n_exec, "source_points": S, "source_points_full": S_full, "planes": planes,
                       "points_per_rank": math.ceil(S / world), "pixel_size": PS, "wavelength": WL, "NA": NA,
                       "parallelism": f"source-point shards x{world}, one all-reduce" if world > 1 else "single GPU",
                       "plan": plan, "image_shape": list(image.shape)},
            "roofline": roofline}
+    if ranks is not None:
+        out["ranks"] = ranks
 
     # ---- CPU baseline leg: the oracle's op-chain port of the reference loop, rank 0, N = 1 only
     if world == 1 and not args.no_cpu_baseline:
@@ -306,10 +414,10 @@ def main():
         # 8 -> 2.1e7, 32 -> 2.6e7, 256 -> 1.6e6 pt*px/s; scripts/cpu_threads_probe.py), so that is the baseline.
         torch.set_num_threads(min(os.cpu_count() or 1, 32))
         K = {256: 64, 1024: 16, 2048: 8, 4096: 4}.get(pn, 8)
-        shifts = L.sourceShifts(bitmap, pn)
+        shifts = L.sourceShifts(w.bitmap, pn)
         sel = shifts[(torch.arange(K, device=dev) * S_full) // K].cpu()
-        p_one = pupil if planes == 1 else pupil[planes // 2]
-        m_cpu, p_cpu = maskFT.cpu(), p_one.cpu()
+        p_one = w.pupil if planes == 1 else w.pupil[planes // 2]
+        m_cpu, p_cpu = w.maskFT.cpu(), p_one.cpu()
         O.abbe_raw(m_cpu, p_cpu, sel[:1], N)                        # warm-up
         times = []
         for _ in range(3):
@@ -317,7 +425,19 @@ def main():
             ref_raw = O.abbe_raw(m_cpu, p_cpu, sel, N)
             times.append(time.perf_counter() - c0)
         tmed = statistics.median(times)
-        gpu_raw = L.abbeIntensity(maskFT, p_one, sel.to(dev), N).cpu()
+        # the parity sample runs the evaluation path of the TIMED step (a handful of points would otherwise fall below
+        # the coarse-grid path's source-count threshold and check the direct kernels instead)
+        old = os.environ.get("LITHO_ABBE_COARSE")
+        os.environ["LITHO_ABBE_COARSE"] = "2" if plan.get("coarse_grid") else "0"
+        try:
+            gpu_raw = L.abbeIntensity(w.maskFT, p_one, sel.to(dev), N).cpu()
+            parity_plan = nat.last_plan()
+        finally:
+            if old is None:
+                del os.environ["LITHO_ABBE_COARSE"]
+            else:
+                os.environ["LITHO_ABBE_COARSE"] = old
+        assert parity_plan["coarse_grid"] == plan.get("coarse_grid"), (parity_plan, plan)
         parity = float((gpu_raw - ref_raw).abs().max() / ref_raw.max())
         out["cpu_baseline"] = {"value": K * pn * pn / tmed, "unit": "source-pt*px/s", "cores": torch.get_num_threads(),
                                "kind": "port",
@@ -325,7 +445,22 @@ def main():
                                          + (f", plane {planes // 2} of {planes}" if planes > 1 else "") +
                                          f", 1 warm-up + 3 reps, median {tmed:.2f} s; oracle/abbe_oracle.py abbe_raw "
                                          "(torch-CPU roll/mul/pad/fftshift/ifft2/ifftshift/crop/abs2/add)",
-                               "gpu_vs_cpu_rel_to_max": parity}
+                               "gpu_vs_cpu_rel_to_max": parity,
+                               "parity_path": {"coarse_grid": parity_plan["coarse_grid"], "kernels": list(nat.last_kernels())}}
+
+    # ---- every other BASELINE configuration, one or two timed steps each (default single-GPU run only)
+    if world == 1 and not args.no_extra and args.workload == "cfg3" and not args.shard and args.points == 0:
+        del w, image
+        torch.cuda.empty_cache()
+        extras = []
+        for name, kw in (("cfg1", dict(steps=5, profile_points=1 << 30)), ("cfg2", dict(steps=2, profile_points=4800)),
+                         ("cfg4", dict(shard=(0, 8), steps=1, warm_points=600, profile_points=600)),
+                         ("cfg5", dict(steps=1, warm_points=240, profile_points=240))):
+            try:
+                extras.append(extra_workload(torch, nat, dev, name, **kw))
+            except Exception as exc:                              # an extra must never cost the headline line
+                extras.append({"workload": name, "error": repr(exc)})
+        out["extra_workloads"] = extras
 
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -129,8 +129,14 @@ int litho_mask_spectrum(const int16_t *geometry, int pn, double epsilon, int N, 
  * launch pair (through-focus stacks), [9]=y-pass groups per plane, [10]=source points per x-pass workgroup,
  * [11]=x-pass kernel family (1 plane-fused k_xpass_abbe, 2 k_xpass_split, 3 k_xpass_rect, 0 fall-backs),
  * [12]=1 when the coarse-grid path ran (pn-point transforms on the grid q = 2 v, fine image reconstructed once
- * per plane), [13..15] reserved. */
+ * per plane), [13]=1 when the y-pass ran a wave-level kernel (k_ypass_rect / k_ypass_wave / k_ypass_pair), [14]=1 when
+ * the pupil's support box lies inside the natural support |k| <= pn/4, [15] reserved. */
 int litho_abbe_last_plan(int64_t fields_host[16]);
+
+/* Names of the x-pass and y-pass kernels the last litho_abbe_accumulate on this thread launched in its source-point
+ * loop, spelt as rocprofv3 prints them without "void litho::" and the argument list (e.g. "k_ypass_rect<11, 8, true>").
+ * Each buffer holds `capacity` bytes (96 is enough); empty strings before the first call. */
+int litho_abbe_last_kernels(char *xpass_host, char *ypass_host, size_t capacity);
 
 /* ---- Per-kernel timing for bench.py: when on, litho_abbe_accumulate brackets every x-pass
  * and y-pass launch with HIP events recorded on `stream` (the first 4096 launch pairs of a call)

@@ -34,6 +34,7 @@ _SIGNATURES = {
     "litho_postprocess": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p]),
     "litho_mask_spectrum": (c_int, [c_void_p, c_int, c_double, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "litho_abbe_last_plan": (c_int, [POINTER(c_int64)]),
+    "litho_abbe_last_kernels": (c_int, [c_void_p, c_void_p, c_size_t]),
     "litho_abbe_set_profiling": (c_int, [c_int]),
     "litho_abbe_last_profile": (c_int, [POINTER(c_double)]),
 }
@@ -140,8 +141,15 @@ def last_plan():
     arr = (c_int64 * 16)()
     lib().litho_abbe_last_plan(arr)
     keys = ("general", "box_row0", "box_col0", "box_rows", "box_cols", "batch", "launches", "variant",
-            "planes_in_flight", "groups_per_plane", "xchunk", "fused_xpass", "coarse_grid")
+            "planes_in_flight", "groups_per_plane", "xchunk", "fused_xpass", "coarse_grid", "wave_ypass", "natural_box")
     return dict(zip(keys, list(arr)))
+
+
+def last_kernels():
+    """(x-pass kernel, y-pass kernel) of the last Abbe call's source-point loop, as rocprofv3 names them."""
+    x, y = ctypes.create_string_buffer(96), ctypes.create_string_buffer(96)
+    check(lib().litho_abbe_last_kernels(x, y, 96), "litho_abbe_last_kernels")
+    return x.value.decode(), y.value.decode()
 
 
 def set_profiling(on: bool):
@@ -153,4 +161,5 @@ def last_profile():
     lib().litho_abbe_last_profile(arr)
     return {"xpass_ms": arr[0], "xpass_launches": int(arr[1]), "xpass_points": int(arr[2]),
             "ypass_ms": arr[3], "ypass_launches": int(arr[4]), "ypass_points": int(arr[5]),
-            "ypass_kernel": "k_ypass_wave" if arr[6] else "k_ypass_acc", "planes_in_flight": int(arr[7])}
+            "wave_ypass": bool(arr[6]), "planes_in_flight": int(arr[7]),
+            "xpass_kernel": last_kernels()[0], "ypass_kernel": last_kernels()[1]}

@@ -197,9 +197,14 @@ __global__ __launch_bounds__(256) void k_nyquist_edges(const float2* __restrict_
         const int dy = shifts[2 * s], dx = shifts[2 * s + 1];
         __syncthreads();
         if (lt < len) {
+            // A zero pupil sample means "outside the support": the shifted mask sample there may lie outside the
+            // grid (the no-wrap test only covers the support box), and 0 * Inf would be a NaN -- no load, exact zero.
             const int i = lo + lt;
-            const float2 mu = edge == 0 ? M[(size_t)(i + dy) * eg.pn + eg.c + eg.h + dx] : M[(size_t)(eg.c + eg.h + dy) * eg.pn + i + dx];
-            const float2 mv = edge == 0 ? M[(size_t)(i + dy) * eg.pn + eg.c - eg.h + dx] : M[(size_t)(eg.c - eg.h + dy) * eg.pn + i + dx];
+            float2 mu = make_float2(0.f, 0.f), mv = make_float2(0.f, 0.f);
+            if (pu.x != 0.f || pu.y != 0.f)
+                mu = edge == 0 ? M[(size_t)(i + dy) * eg.pn + eg.c + eg.h + dx] : M[(size_t)(eg.c + eg.h + dy) * eg.pn + i + dx];
+            if (pvv.x != 0.f || pvv.y != 0.f)
+                mv = edge == 0 ? M[(size_t)(i + dy) * eg.pn + eg.c - eg.h + dx] : M[(size_t)(eg.c - eg.h + dy) * eg.pn + i + dx];
             su[edge][lt] = cmul(pu, mu);
             sv[edge][lt] = cmul(pvv, mv);
         }
@@ -306,6 +311,15 @@ static size_t t_budget(int pn)
     return b;
 }
 
+// Sizes at which the coarse-grid path exists (its regions of the workspace are empty elsewhere: 1.5 GiB at 8192^2)
+static bool coarse_eligible(int pn, int N)
+{
+    return N == 2 * pn && (pn == 256 || pn == 512 || pn == 1024 || pn == 2048 || pn == 4096);
+}
+static size_t ic_bytes(int pn, int N) { return coarse_eligible(pn, N) ? (size_t)COARSE_PLANES * pn * pn * sizeof(float) : 0; }
+static size_t chat_bytes(int pn, int N) { return coarse_eligible(pn, N) ? (size_t)pn * pn * sizeof(float2) : 0; }
+static size_t gam_bytes(int pn, int N) { return coarse_eligible(pn, N) ? gam_float2(pn) * sizeof(float2) : 0; }
+
 static size_t workspace_bytes(int pn, int N)
 {
     const size_t nt = (pn + 3) / 4;
@@ -313,9 +327,9 @@ static size_t workspace_bytes(int pn, int N)
     b += align_up((size_t)N * sizeof(float2), 256);
     b += align_up((size_t)pn * sizeof(float2), 256);
     b += align_up((size_t)g_cap(pn) * nt * 4 * pn * sizeof(float), 256);
-    b += align_up((size_t)COARSE_PLANES * pn * pn * sizeof(float), 256);
-    b += align_up((size_t)pn * pn * sizeof(float2), 256);
-    b += align_up(gam_float2(pn) * sizeof(float2), 256);
+    b += align_up(ic_bytes(pn, N), 256);
+    b += align_up(chat_bytes(pn, N), 256);
+    b += align_up(gam_bytes(pn, N), 256);
     b += align_up(t_budget(pn), 256);
     return b;
 }
@@ -329,9 +343,9 @@ static bool carve(void* ws, size_t bytes, int pn, int N, Workspace& w)
     w.twtab = (float2*)p; p += align_up((size_t)N * sizeof(float2), 256);
     w.twtab2 = (float2*)p; p += align_up((size_t)pn * sizeof(float2), 256);
     w.slab = (float*)p; p += align_up((size_t)g_cap(pn) * nt * 4 * pn * sizeof(float), 256);
-    w.ic = (float*)p; p += align_up((size_t)COARSE_PLANES * pn * pn * sizeof(float), 256);
-    w.chat = (float2*)p; p += align_up((size_t)pn * pn * sizeof(float2), 256);
-    w.gam = (float2*)p; p += align_up(gam_float2(pn) * sizeof(float2), 256);
+    w.ic = (float*)p; p += align_up(ic_bytes(pn, N), 256);
+    w.chat = (float2*)p; p += align_up(chat_bytes(pn, N), 256);
+    w.gam = (float2*)p; p += align_up(gam_bytes(pn, N), 256);
     w.T = (float2*)p;
     w.t_bytes = t_budget(pn);
     return true;
@@ -474,6 +488,7 @@ struct MarkList {
 struct AbbePlan {
     PassGeom g;
     int general, variant;       // 1: roll kept on P (wrapping shifts); kernel specialisation (-1 generic, else log2(N/pn))
+    bool natural_box;           // the pupil's support box lies inside |k| <= pn/4 (and no shift wraps)
     int r0, c0, h, wdt;         // pupil support box (rows r0 .. r0+h, columns c0 .. c0+wdt)
     bool wave_y;                // y-pass by the wave-level family (k_ypass_wave / k_ypass_pair / k_ypass_rect)
     bool split_x, rect_x, fused_x;   // x-pass: k_xpass_split / k_xpass_rect / plane-fused k_xpass_abbe (else per-plane fall-backs)
@@ -492,6 +507,13 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
     PassGeom& g = pp.g;
     make_geom(g, pn, N, r0, c0, h, wdt, general, kn.tile > 0 ? kn.tile : 4);
     const int variant = pick_variant(g, kn);
+    // The wave-level kernels, the split x-pass and the coarse-grid path hard-wire the NATURAL support |k| <= pn/4 (the
+    // unit disk of the [-2,2) sigma grid): they load only the slots that cover it and the coarse grid assumes
+    // |kappa| <= pn/2.  pick_variant's 16-slot masks are coarser than that (a one-sided box reaching k = 3 pn/8 - 1
+    // still has the natural slot set), so the box itself is checked; anything wider runs the radix-16 kernels, whose
+    // windows are runtime-predicated inside the admitted slots.
+    const int cc = pn / 2, hh = pn / 4;
+    const bool natural_box = !general && r0 >= cc - hh && r0 + h - 1 <= cc + hh && c0 >= cc - hh && c0 + wdt - 1 <= cc + hh;
 
     // wave-level y-pass kernels, N = 2 pn: N = 512, 1024, 2048 k_ypass_rect (8, 4, 2 columns per wave; fall-back
     // k_ypass_wave with S = 32 for 1024 and 2048), N = 4096 k_ypass_wave (S = 64), N = 8192 k_ypass_pair
@@ -503,7 +525,7 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
     // N = pn (the coarse-grid transform, and pixel sizes that give N = pn): full-output variants of the same kernels
     const bool full_ok = (pn == N) && (N == 1024 || N == 2048 || N == 4096 ||
                                        ((N == 512 || N == 256) && (kn.tile <= 0 || kn.tile == 8)));
-    const bool w64_shape = ((w64_ok && variant == 1) || (full_ok && variant == 0)) && kn.w64;
+    const bool w64_shape = ((w64_ok && variant == 1) || (full_ok && variant == 0)) && kn.w64 && natural_box;
     // T tile width.  The x-pass's T stores are bound by the memory system's rate for partial-line writes: measured
     // (scripts/ubench/write_bw.hip) 2.2 TB/s for 32-byte granules (4-column tiles), 3.4 TB/s for 64-byte granules
     // (8 columns), 5.2 TB/s for whole 128-byte lines.  The wave kernels read 8-column tiles at no extra cost, the
@@ -591,7 +613,7 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
     }
 
     // N = 8192 = 2 pn: each row as two 4096-point transforms (k_xpass_split) instead of the 8192-point engine
-    pp.split_x = !general && variant == 1 && N == 8192 && g.tcl >= 2 && kn.xsplit;
+    pp.split_x = !general && variant == 1 && N == 8192 && g.tcl >= 2 && kn.xsplit && natural_box;
     // Several box rows per wave on the wave-level engine, whole-line T stores (k_xpass_rect).  Measured (us per source
     // point, radix-16 x-pass -> k_xpass_rect): N = 1024 0.57 -> 0.36, N = 2048 1.43 -> 1.46, N = 512 0.27 -> 0.26: its
     // loads are not prefetched (no registers left), so it only pays where the radix-16 engine is at its weakest.
@@ -599,11 +621,12 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
     // The same kernel with every bin kept serves the coarse-grid transforms (variant 0, N = pn) -- only on request:
     // with twice the loads and stores per wave it is SLOWER than the radix-16 x-pass at every size (coarse-grid x-pass,
     // us per point, radix-16 -> rect: N' = 512 0.28 -> 0.32, 1024 1.25 -> 1.49, 2048 4.73 -> 6.77).
-    pp.rect_x = !general && ((variant == 1 && pn * 2 == N) || (variant == 0 && pn == N)) && N >= 512 && N <= 2048 &&
+    pp.rect_x = natural_box && ((variant == 1 && pn * 2 == N) || (variant == 0 && pn == N)) && N >= 512 && N <= 2048 &&
                 g.tcl == 3 && (kn.xrect >= 2 || (kn.xrect == 1 && variant == 1 && N == 1024));
     const bool wave_x_optin = wave_y && variant == 1 && N == 4096 && kn.w64x && g.tcl == 2;      // k_xpass_w64 (slower, parity-tested)
     pp.fused_x = !pp.split_x && !pp.rect_x && !general && variant >= 0 && !wave_x_optin;
     pp.general = general; pp.variant = variant; pp.r0 = r0; pp.c0 = c0; pp.h = h; pp.wdt = wdt;
+    pp.natural_box = natural_box;
     pp.wave_y = wave_y; pp.PC = PC; pp.G = G; pp.xchunk = xchunk; pp.bs = bs;
     return LITHO_OK;
 }
@@ -753,8 +776,8 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     // 4096^2), so short source lists stay on the direct path: break-even measured at S = 14,000 (256^2), 1,200
     // (512^2), < 500 (1024^2), about 100 (2048^2, 4096^2); scripts/total_time.py.  LITHO_ABBE_COARSE = 2 ignores S.
     const int64_t s_min = pn == 256 ? 16384 : pn == 512 ? 1536 : pn == 1024 ? 384 : 128;
-    bool coarse = kn.coarse && (kn.coarse >= 2 || S >= s_min) && N == 2 * pn && pp.variant == 1 && !pp.general &&
-                  pl[13] == 0 && (pn == 256 || pn == 512 || pn == 1024 || pn == 2048 || pn == 4096);
+    bool coarse = kn.coarse && (kn.coarse >= 2 || S >= s_min) && coarse_eligible(pn, N) && pp.variant == 1 && pp.natural_box &&
+                  pl[13] == 0;
     if (coarse) {
         eg.pn = pn; eg.c = pn / 2; eg.h = pn / 4;
         eg.lo[0] = pl[10] >= pl[9] ? pl[9] : 0;   eg.len[0] = pl[10] >= pl[9] ? pl[10] - pl[9] + 1 : 0;
@@ -808,6 +831,8 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     g_last_plan[8] = run.PC; g_last_plan[9] = run.G; g_last_plan[10] = run.xchunk;
     g_last_plan[11] = run.fused_x ? 1 : (run.split_x ? 2 : (run.rect_x ? 3 : 0));
     g_last_plan[12] = coarse ? 1 : 0;
+    g_last_plan[13] = run.wave_y ? 1 : 0;
+    g_last_plan[14] = pp.natural_box ? 1 : 0;
     return LITHO_OK;
 }
 

@@ -13,9 +13,30 @@ void set_last_error(const char* what, hipError_t e)
     snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
     (void)hipGetLastError();     // clear the sticky error so later calls start clean
 }
+struct KernelNote {
+    const char* fmt;
+    int a[4];
+};
+static thread_local KernelNote g_note[2] = {{nullptr, {0, 0, 0, 0}}, {nullptr, {0, 0, 0, 0}}};
+void note_kernel(int pass, const char* fmt, int a0, int a1, int a2, int a3)
+{
+    if (pass < 0 || pass > 1) return;
+    g_note[pass] = KernelNote{fmt, {a0, a1, a2, a3}};
+}
 }  // namespace litho
 
 extern "C" {
+int litho_abbe_last_kernels(char* xpass_host, char* ypass_host, size_t capacity)
+{
+    if (!xpass_host || !ypass_host || capacity == 0) return LITHO_E_ARG;
+    char* dst[2] = {xpass_host, ypass_host};
+    for (int p = 0; p < 2; ++p) {
+        const litho::KernelNote& n = litho::g_note[p];
+        if (n.fmt) snprintf(dst[p], capacity, n.fmt, n.a[0], n.a[1], n.a[2], n.a[3]);
+        else dst[p][0] = 0;
+    }
+    return LITHO_OK;
+}
 int litho_version(void) { return 100; }
 #ifdef LITHO_DIAG_BUILD
 const char* litho_target_arch(void) { return "gfx950-diag"; }      // timing-diagnostic build: results may be wrong

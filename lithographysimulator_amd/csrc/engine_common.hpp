@@ -5,6 +5,10 @@
 namespace litho {
 // Records "<expr>: <hip error string>" for litho_last_error() (thread local).
 void set_last_error(const char* what, hipError_t e);
+// Remembers (thread local, formatted lazily by litho_abbe_last_kernels) which kernel the Abbe loop launched last for
+// pass 0 (x) / 1 (y): fmt is a string literal with up to four %d, spelt the way rocprofv3 prints the kernel, without
+// "void litho::" and the argument list -- so bench.py and the profiles/ summaries can be matched by name.
+void note_kernel(int pass, const char* fmt, int a0 = 0, int a1 = 0, int a2 = 0, int a3 = 0);
 }  // namespace litho
 
 #define HIP_TRY(expr)                                   \

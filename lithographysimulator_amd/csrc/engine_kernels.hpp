@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "engine_common.hpp"
 #include "fft_core.hpp"
 #include "wave_fft.hpp"
 
@@ -730,7 +731,7 @@ static hipError_t set_lds(LdsOnce& once, K kern, size_t bytes)
     return e;
 }
 
-// defined (and explicitly instantiated for 9 <= LOG2N <= 13) in instw_*.hip
+// defined (and explicitly instantiated for 8 <= LOG2N <= 13) in instw_*.hip
 template <int LOG2N>
 hipError_t launch_ypass_wave(const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb, int planes,
                              int G, int gstride, hipStream_t st);
@@ -754,6 +755,7 @@ struct SizeImpl {
         // L == 1: grid.x padded to a multiple of 32 for the XCD-aware row mapping in the kernel
         dim3 grid(LC::L == 1 ? (g.rows + 31) / 32 * 32 : (g.rows + LC::L - 1) / LC::L, (nb + chunk - 1) / chunk);
         hipLaunchKernelGGL(kern, grid, dim3(LC::THREADS), LC::LDS_BYTES, st, P, M, shifts, T, tw, g, nb, chunk);
+        note_kernel(0, PRUNED ? "k_xpass_abbe<%d, %d, true, %d>" : "k_xpass_abbe<%d, %d, false, %d>", LOG2N, RL, NP);
         return hipGetLastError();
     }
     template <int RL>
@@ -788,6 +790,7 @@ struct SizeImpl {
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3((g.rows + LC::L - 1) / LC::L, nb), dim3(LC::THREADS), LC::LDS_BYTES, st, ld, T,
                            tw, g);
+        note_kernel(0, "k_xpass<%d, 1, litho::AbbeLoader>", LOG2N);
         return hipGetLastError();
     }
     static hipError_t xpass_split(const float2* P, const float2* M, const int* shifts, float2* T, const float2* tw,
@@ -801,6 +804,7 @@ struct SizeImpl {
             if (e != hipSuccess) return e;
             dim3 grid((g.rows + 31) / 32 * 32, (nb + chunk - 1) / chunk);
             hipLaunchKernelGGL(kern, grid, dim3(LH::THREADS), LH::LDS_BYTES, st, P, M, shifts, T, tw, g, nb, chunk);
+            note_kernel(0, "k_xpass_split<%d>", LOG2N);
             return hipGetLastError();
         } else {
             return hipErrorNotSupported;
@@ -833,6 +837,7 @@ struct SizeImpl {
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3((g.nt + LC::L - 1) / LC::L, planes * G), dim3(LC::THREADS), LC::LDS_BYTES, st, T,
                            slab, tw, g, nb, G, gstride);
+        note_kernel(1, PRUNED ? "k_ypass_acc<%d, %d, true>" : "k_ypass_acc<%d, %d, false>", LOG2N, RL);
         return hipGetLastError();
     }
     static hipError_t ypass_acc(int variant, const float2* T, float* slab, const float2* tw, const PassGeom& g, int nb,
@@ -877,6 +882,7 @@ struct SizeImpl {
             const int wgs = items < 512 ? items : 512;               // 256 CUs x 2 resident workgroups
             const int per = (items + wgs - 1) / wgs;
             hipLaunchKernelGGL(kern, dim3((items + per - 1) / per), dim3(256), lds, st, P, M, shifts, T, tw, g, nb, per);
+            note_kernel(0, "k_xpass_w64<%d>", LOG2N);
             return hipGetLastError();
         } else {
             return hipErrorNotSupported;

@@ -1,7 +1,10 @@
 // wave_kernels.hpp -- the wave-level y-pass kernels (one wavefront, a pair of wavefronts, or several columns per
-// wavefront) and their launcher.  Included ONLY by instw_*.hip: these translation units can take their own
-// scheduling strategy (Makefile: max-ilp for N = 4096, 2 % faster there; the pair kernel and the workgroup-level
-// FFT kernels prefer the default), so the kernels must not be instantiated anywhere else.
+// wavefront), the multi-row x-pass built on the same engine, and their launchers.  Included ONLY by instw_*.hip
+// (N = 256 .. 8192): these translation units can take their own scheduling flags (Makefile WAVEFLAGS_<log2 N>), so the
+// kernels must not be instantiated anywhere else.  Today every one of them is built with the default strategy:
+// max-ilp was 2 % faster for the half-output k_ypass_wave<12> but makes its full-output variant spill 73 registers,
+// and is 3-10 % slower for k_ypass_rect<11,.,true> and k_ypass_pair (A/B numbers: Makefile, profiles/r02_tuning_sweeps.txt).
+// (Makefile INSTFLAGS_13 = max-ilp applies to inst_13.o, the radix-16 unit with the N = 8192 split x-pass, not to these.)
 #pragma once
 #include "engine_kernels.hpp"
 
@@ -454,12 +457,14 @@ hipError_t launch_xpass_rect(const float2* P, const float2* M, const int* shifts
             hipError_t e = set_lds(once_full, kern, lds);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, P, M, shifts, T, tw, g, nb, chunk);
+            note_kernel(0, "k_xpass_rect<%d, true>", LOG2N);
             return hipGetLastError();
         }
         auto kern = k_xpass_rect<LOG2N>;
         hipError_t e = set_lds(once, kern, lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, P, M, shifts, T, tw, g, nb, chunk);
+        note_kernel(0, "k_xpass_rect<%d, false>", LOG2N);
         return hipGetLastError();
     } else {
         return hipErrorNotSupported;
@@ -480,6 +485,7 @@ static hipError_t launch_ypass_wave_tc(const float2* T, float* slab, const float
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, 4>(g.pn), planes * G), dim3(256), ldsf, st, T, slab, tw, g, nb, G,
                                gstride);
+            note_kernel(1, "k_ypass_wave<%d, %d, true>", LOG2N, TC);
             return hipGetLastError();
         } else if constexpr (LOG2N >= 8 && LOG2N <= 11) {
             constexpr int NL = 4096 >> LOG2N;
@@ -490,7 +496,8 @@ static hipError_t launch_ypass_wave_tc(const float2* T, float* slab, const float
                 if (e != hipSuccess) return e;
                 hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, 4 * NL>(g.pn), planes * G), dim3(256), lds4, st, T, slab, tw,
                                    g, nb, G, gstride);
-                return hipGetLastError();
+                note_kernel(1, "k_ypass_rect<%d, %d, true>", LOG2N, TC);
+            return hipGetLastError();
             }
         }
         return hipErrorNotSupported;
@@ -502,7 +509,8 @@ static hipError_t launch_ypass_wave_tc(const float2* T, float* slab, const float
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, 2>(g.pn), planes * G), dim3(256), lds4, st, T, slab, tw, g, nb, G,
                            gstride);
-        return hipGetLastError();
+        note_kernel(1, "k_ypass_pair<%d, %d>", LOG2N, TC);
+            return hipGetLastError();
     } else if constexpr (LOG2N >= 9 && LOG2N <= 11) {
         constexpr int NL = 4096 >> LOG2N;                       // columns per wave of k_ypass_rect
         if constexpr (NL <= TC) {
@@ -513,7 +521,8 @@ static hipError_t launch_ypass_wave_tc(const float2* T, float* slab, const float
                 if (e != hipSuccess) return e;
                 hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, 4 * NL>(g.pn), planes * G), dim3(256), lds4, st, T, slab, tw,
                                    g, nb, G, gstride);
-                return hipGetLastError();
+                note_kernel(1, "k_ypass_rect<%d, %d, false>", LOG2N, TC);
+            return hipGetLastError();
             }
         }
         if constexpr (LOG2N >= 10) {
@@ -524,6 +533,7 @@ static hipError_t launch_ypass_wave_tc(const float2* T, float* slab, const float
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, WS::COLS>(g.pn), planes * G), dim3(WS::THREADS),
                                WS::LDS_BYTES, st, T, slab, tw, g, nb, G, gstride);
+            note_kernel(1, "k_ypass_wave<%d, %d, false>", LOG2N, TC);
             return hipGetLastError();
         } else {
             return hipErrorNotSupported;
@@ -536,6 +546,7 @@ static hipError_t launch_ypass_wave_tc(const float2* T, float* slab, const float
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, WS::COLS>(g.pn), planes * G), dim3(WS::THREADS), WS::LDS_BYTES,
                            st, T, slab, tw, g, nb, G, gstride);
+        note_kernel(1, "k_ypass_wave<%d, %d, false>", LOG2N, TC);
         return hipGetLastError();
     } else {
         return hipErrorNotSupported;

@@ -443,12 +443,17 @@ def _test_stack_plane_chunk_knob_and_generic_variant(L, dev, monkeypatch):
     assert rel_max(ref[3], chain) < TOL_IMAGE_MAX
 
 
+@pytest.mark.parametrize("path", ["coarse", "direct"])
 @pytest.mark.parametrize("tag,pn,skind,ab", [("cfg2", 1024, "annular", [0, 0, 0, 0, 100]), ("cfg3", 2048, "quasar", DEMO_AB)])
-def test_contiguous_shard_vs_golden(golden, L, dev, tag, pn, skind, ab):
+def test_contiguous_shard_vs_golden(golden, L, dev, monkeypatch, tag, pn, skind, ab, path):
     """Shard-sized runs of CONSECUTIVE source points at the BASELINE sizes (config 2: 2048 points, config 3: 512
     points), accumulated by the reference's own sequential fp32 loop (golden g10): many full batches through the
-    default kernels, compared on a centre crop, every row/column sum, the maximum and the total."""
+    DEFAULT evaluation (these source lists are long enough for the coarse-grid path: asserted) and through the direct
+    N-point path, compared on a centre crop, every row/column sum, the maximum and the total."""
+    from lithographysimulator_amd import _native as nat
     from lithographysimulator_amd.synthetic import bernoulli_mask
+    if path == "direct":
+        monkeypatch.setenv("LITHO_ABBE_COARSE", "0")
     g = golden("g10_contiguous_shards.npz")
     lo, hi, S = (int(v) for v in g[f"{tag}_range"])
     mask = L.Mask(bernoulli_mask(pn), PS, dev)
@@ -461,13 +466,51 @@ def test_contiguous_shard_vs_golden(golden, L, dev, tag, pn, skind, ab):
     assert np.array_equal(sel[[0, -1]].cpu().numpy(), g[f"{tag}_first_last_shift"])
     pf = L.Pupil(pn, WL, NA, f16(ab), dev).generatePupilFunction()
     raw = L.abbeIntensity(mft, pf, sel, N).cpu()
+    plan = nat.last_plan()
+    assert plan["coarse_grid"] == (1 if path == "coarse" else 0) and plan["launches"] > 8, plan
     e = rel_max(crop_center(raw), g[f"{tag}_raw_crop"])
-    print(f"{tag} shard [{lo},{hi}): crop error rel-to-max {e:.2e}")
+    print(f"{tag} shard [{lo},{hi}) {path} path: crop error rel-to-max {e:.2e}")
     assert e < TOL_IMAGE_MAX
     assert np.allclose(raw.double().sum(1).numpy(), g[f"{tag}_raw_rowsum"], rtol=2e-5)
     assert np.allclose(raw.double().sum(0).numpy(), g[f"{tag}_raw_colsum"], rtol=2e-5)
     assert abs(float(raw.max()) / float(g[f"{tag}_raw_max"]) - 1) < 2e-5
     assert abs(float(raw.double().sum()) / float(g[f"{tag}_raw_sum"]) - 1) < 2e-6
+
+
+@pytest.mark.parametrize("path", ["coarse", "direct"])
+def test_consecutive_shard_4096_vs_golden(golden, L, dev, monkeypatch, path):
+    """BASELINE config 4's size: 64 CONSECUTIVE source points [800000, 800064) of the 4096^2 annular list, run by the
+    reference's own abbeImage (golden g12): several launch batches of the 4096-point kernels, raw intensity and the
+    4094^2 post-processed image (quirk Q5), default (coarse-grid) and direct evaluation."""
+    from lithographysimulator_amd import _native as nat
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    g = golden("g12_shard4096.npz")
+    pn = 4096
+    monkeypatch.setenv("LITHO_ABBE_COARSE", "2" if path == "coarse" else "0")
+    lo, hi, S = (int(v) for v in g["cfg4shard_range"])
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateAnnular(), pn)
+    assert sh.shape[0] == S
+    sel = sh[lo:hi]
+    assert np.array_equal(sel[[0, -1]].cpu().numpy(), g["cfg4shard_first_last_shift"])
+    pf = L.Pupil(pn, WL, NA, f16([0, 0, 0, 0, 100]), dev).generatePupilFunction()
+    raw = L.abbeIntensity(mft, pf, sel, N)
+    plan = nat.last_plan()
+    assert plan["coarse_grid"] == (1 if path == "coarse" else 0) and plan["launches"] >= 4, plan
+    final = L.postProcess(raw, eps).cpu()
+    raw = raw.cpu()
+    assert tuple(final.shape) == (4094, 4094) == tuple(g["cfg4shard_final_shape"])
+    for tag, img in (("raw", raw), ("final", final)):
+        e_crop = rel_max(crop_center(img), g[f"cfg4shard_{tag}_crop"])
+        e_grid = float(np.abs(img[::32, ::32].numpy().astype(np.float64) - g[f"cfg4shard_{tag}_stride32"]).max() / g[f"cfg4shard_{tag}_max"])
+        print(f"4096^2 shard {path} path, {tag}: crop {e_crop:.2e}, stride-32 grid {e_grid:.2e} (rel to max)")
+        assert e_crop < TOL_IMAGE_MAX and e_grid < TOL_IMAGE_MAX
+        assert np.allclose(img.double().sum(1).numpy(), g[f"cfg4shard_{tag}_rowsum"], rtol=2e-5, atol=2e-6 * float(g[f"cfg4shard_{tag}_rowsum"].max()))
+        assert np.allclose(img.double().sum(0).numpy(), g[f"cfg4shard_{tag}_colsum"], rtol=2e-5, atol=2e-6 * float(g[f"cfg4shard_{tag}_colsum"].max()))
+        assert abs(float(img.max()) / float(g[f"cfg4shard_{tag}_max"]) - 1) < 2e-5
+        assert abs(float(img.double().sum()) / float(g[f"cfg4shard_{tag}_sum"]) - 1) < 2e-6
 
 
 def test_full_source_additivity_config2(L, dev):
@@ -619,9 +662,9 @@ def _test_wave_per_line_and_radix16_ypass_agree_2048(L, dev, monkeypatch):
     nat.set_profiling(True)
     try:
         ref = L.abbeIntensity(mft, pf, sel, N).cpu()
-        assert nat.last_profile()["ypass_kernel"] == "k_ypass_wave" and nat.last_plan()["variant"] == 1
+        assert nat.last_kernels()[1].startswith("k_ypass_wave<12") and nat.last_plan()["variant"] == 1
         r16 = _with_env(monkeypatch, L, {"LITHO_ABBE_W64": "0"}, lambda: L.abbeIntensity(mft, pf, sel, N).cpu())
-        assert nat.last_profile()["ypass_kernel"] == "k_ypass_acc"
+        assert nat.last_kernels()[1].startswith("k_ypass_acc<")
     finally:
         nat.set_profiling(False)
     assert rel_max(r16, ref) < 2e-6
@@ -692,7 +735,7 @@ def _test_small_size_kernels_agree(L, dev, monkeypatch, pn):
     nat.set_profiling(True)
     try:
         ref = L.abbeIntensity(mft, pf, sel, N).cpu()
-        assert nat.last_profile()["ypass_kernel"] == "k_ypass_wave"          # the wave-level family (k_ypass_rect here)
+        assert nat.last_plan()["wave_ypass"] == 1 and nat.last_kernels()[1].startswith("k_ypass_rect<")
     finally:
         nat.set_profiling(False)
     assert nat.last_plan()["fused_xpass"] == (3 if pn == 512 else 1)    # k_xpass_rect (4 box rows per wave) at N = 1024
@@ -727,10 +770,10 @@ def _test_8192_kernels_agree_4096(L, dev, monkeypatch):
     nat.set_profiling(True)
     try:
         new = L.abbeIntensity(mft, pf, sel, N).cpu()
-        assert nat.last_plan()["fused_xpass"] == 2 and nat.last_profile()["ypass_kernel"] == "k_ypass_wave"
+        assert nat.last_plan()["fused_xpass"] == 2 and nat.last_kernels() == ("k_xpass_split<13>", "k_ypass_pair<13, 8>")
         old = _with_env(monkeypatch, L, {"LITHO_ABBE_W64_8192": "0", "LITHO_ABBE_XSPLIT": "0"},
                         lambda: L.abbeIntensity(mft, pf, sel, N).cpu())
-        assert nat.last_plan()["fused_xpass"] == 1 and nat.last_profile()["ypass_kernel"] == "k_ypass_acc"
+        assert nat.last_plan()["fused_xpass"] == 1 and nat.last_kernels()[1].startswith("k_ypass_acc<13")
     finally:
         nat.set_profiling(False)
     assert rel_max(new, old) < 2e-6
@@ -781,6 +824,46 @@ def test_wide_pupil_forces_generic_variant_1024(L, dev):
     assert plan["variant"] == -1 and plan["general"] == 0 and plan["box_rows"] > pn // 2 + 1
     ref = o.abbe_raw(mft, pupil, shifts, N)
     assert rel_max(got, ref) < TOL_IMAGE_MAX and rel_l2(got, ref) < TOL_IMAGE_L2
+
+
+@pytest.mark.parametrize("pn,side", [(1024, "cols_hi"), (1024, "rows_lo"), (512, "cols_hi"), (2048, "rows_hi")])
+def test_one_sided_pupil_stays_off_the_natural_box_kernels(L, dev, monkeypatch, pn, side):
+    """A decentred pupil whose support reaches 40 samples beyond |k| = pn/4 on ONE side still has the 'natural' 16-slot
+    masks (they admit k up to 3 pn/8 - 1), but the wave-level kernels, the split x-pass and the coarse grid hard-wire
+    |k| <= pn/4: such a box must run the radix-16 kernels on the direct path -- by default and with the coarse-grid path
+    requested -- and match the oracle."""
+    from lithographysimulator_amd import _native as nat
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    o = O()
+    N = 2 * pn
+    c, h, ext = pn // 2, pn // 4, 40
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    pupil = L.Pupil(pn, WL, NA, f16([0, 0, 0, 0, 60]), dev).generatePupilFunction().clone()
+    gen = torch.Generator().manual_seed(5)
+    strip = torch.polar(0.5 + 0.5 * torch.rand(h, ext, generator=gen), 6.28 * torch.rand(h, ext, generator=gen)).to(torch.complex64).to(dev)
+    if side == "cols_hi":
+        pupil[c - h // 2:c + h // 2, c + h + 1:c + h + 1 + ext] = strip
+    elif side == "rows_lo":
+        pupil[c - h - ext:c - h, c - h // 2:c + h // 2] = strip.T
+    else:
+        pupil[c + h + 1:c + h + 1 + ext, c - h // 2:c + h // 2] = strip.T
+    sh = L.sourceShifts(L.LightSource(0.4, 0.7, pn, NA, device=dev).generateAnnular(), pn)
+    K = 6 if pn >= 2048 else 12
+    sel = sh[(torch.arange(K, device=dev) * sh.shape[0]) // K].contiguous()
+    ref = o.abbe_raw(mft.cpu(), pupil.cpu(), sel.cpu(), N)
+    for env in ({}, {"LITHO_ABBE_COARSE": "2"}):
+        got = _with_env(monkeypatch, L, env, lambda: L.abbeIntensity(mft, pupil, sel, N)).cpu()
+        plan = nat.last_plan()
+        # on the high side the 16-slot masks still say "natural" (variant 1: the case that used to slip through); on
+        # the low side slot 13 is touched and the generic variant (-1) takes over -- either way no natural-box kernel
+        assert plan["coarse_grid"] == 0 and plan["general"] == 0 and plan["wave_ypass"] == 0 and plan["natural_box"] == 0, plan
+        assert plan["variant"] == (1 if side.endswith("_hi") else -1), plan
+        assert nat.last_kernels()[1].startswith("k_ypass_acc<") and nat.last_kernels()[0].startswith("k_xpass_abbe<"), nat.last_kernels()
+        assert max(plan["box_rows"], plan["box_cols"]) == 2 * h + 1 + ext, plan
+        e = rel_max(got, ref)
+        print(f"{pn}^2 one-sided pupil ({side}), env {env}: rel-to-max {e:.2e}")
+        assert e < TOL_IMAGE_MAX and rel_l2(got, ref) < TOL_IMAGE_L2
 
 
 def test_largest_size_8192_self_consistent(L, dev, monkeypatch):

@@ -31,12 +31,20 @@ def test_bench_json_contract():
     assert rl["bound"] == "valu" and rl["unit"] == "TFLOP/s" and rl["peak"] == 157.3
     assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-9 and 0 < rl["frac"] <= 1
     assert 0 < rl["pipeline"]["frac"] <= 1
-    hbm = rl["hbm"]
-    assert hbm["peak"] == 8000.0 and "effective_40B" in hbm and "measured" in hbm
+    # the memory-side view: top-level keys, labelled for what they are (L2 <-> fabric requests, Infinity-Cache hits included)
+    for key in ("fabric_GBs", "fabric_frac", "effective_40B_GBs", "effective_40B_over_peak", "copy_ceiling_GBs", "hbm_peak_GBs"):
+        assert key in rl, key
+    assert rl["hbm_peak_GBs"] == 8000.0 and "hbm" not in rl
     if rl["traffic"] is not None:
-        assert hbm["measured_frac"] <= 1
+        assert rl["fabric_frac"] <= 1
+    # kernel names come from the library (litho_abbe_last_kernels), spelt as rocprofv3 prints them
+    assert rl["kernel"].startswith(("k_ypass_", "k_xpass_")) and "<" in rl["kernel"]
+    assert rl["kernels"]["xpass"]["kernel"].startswith("k_xpass") and rl["kernels"]["ypass"]["kernel"].startswith("k_ypass")
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["gpu_vs_cpu_rel_to_max"] < 2e-5
+    # the parity sample ran the evaluation path of the timed step
+    assert cb["parity_path"]["coarse_grid"] == r["config"]["plan"]["coarse_grid"]
+    assert "extra_workloads" not in r                           # only the default cfg3 run carries them
 
 
 def test_bench_launches_its_own_ranks():
@@ -56,6 +64,10 @@ def test_bench_launches_its_own_ranks():
     assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["config"]["points_per_rank"] == 1617
     assert r["config"]["source_points"] == 3233 and r["value"] > 1e9 and "cpu_baseline" not in r
     assert r["config"]["parallelism"].startswith("source-point shards x2")
+    rk = r["ranks"]                                               # per-rank view of one instrumented step
+    assert len(rk["step_ms"]) == 2 and len(rk["compute_ms"]) == 2 and len(rk["allreduce_wait_ms"]) == 2
+    assert rk["source_points"] == [1617, 1616] and rk["allreduce_bytes"] == 256 * 256 * 4
+    assert rk["step_ms_max"] >= rk["step_ms_min"] > 0 and min(rk["compute_ms"]) > 0
 
 
 def test_bench_rank_failure_does_not_hang():

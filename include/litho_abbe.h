@@ -117,6 +117,14 @@ int litho_postprocess_size(int pn, double epsilon, int *n_out_host);
 int litho_postprocess(const float *raw, int planes, int pn, double epsilon, float *out,
                       void *stream);
 
+/* ---- The same pass with a constant-threshold resist model fused in (the reference lists "photoresist response
+ * modeling, simple or otherwise" as an open goal, README.md:21; there is no reference code, so the definition is
+ * this one): resist[p][y][x] = 1 where fp32(image * gain) >= fp32(threshold), else 0, on the post-processed
+ * [planes,n_out,n_out] grid; gain = exposure dose (or dose / S for a normalised image).  out (the fp32 aerial image)
+ * may be NULL when only the contour mask is wanted; resist uint8, required. */
+int litho_postprocess_resist(const float *raw, int planes, int pn, double epsilon, double gain, double threshold,
+                             float *out, uint8_t *resist, void *stream);
+
 /* ---- Mask spectrum pre-step: Mask._ffFraunhofer (mask.py:74-90).  geometry int16
  * [pn,pn]; spectrum complex64 [pn,pn].  Uses the same workspace as the Abbe calls. */
 int litho_mask_spectrum(const int16_t *geometry, int pn, double epsilon, int N, void *spectrum,

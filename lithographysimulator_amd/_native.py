@@ -32,6 +32,7 @@ _SIGNATURES = {
     "litho_abbe_field": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "litho_postprocess_size": (c_int, [c_int, c_double, POINTER(c_int)]),
     "litho_postprocess": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p]),
+    "litho_postprocess_resist": (c_int, [c_void_p, c_int, c_int, c_double, c_double, c_double, c_void_p, c_void_p, c_void_p]),
     "litho_mask_spectrum": (c_int, [c_void_p, c_int, c_double, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "litho_abbe_last_plan": (c_int, [POINTER(c_int64)]),
     "litho_abbe_last_kernels": (c_int, [c_void_p, c_void_p, c_size_t]),

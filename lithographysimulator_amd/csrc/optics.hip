@@ -242,8 +242,13 @@ __device__ __forceinline__ float bilinear_at(const TIn* __restrict__ img, int n_
     return ly0 * (lx0 * at(y0, x0) + lx1 * at(y0, x1)) + ly1 * (lx0 * at(y1, x0) + lx1 * at(y1, x1));
 }
 
+// RESIST: the constant-threshold resist model fused into the same pass (README.md:21 of the reference lists "photoresist
+// response modeling, simple or otherwise" as an open goal; there is no reference code to match): the resampled
+// intensity is multiplied by `gain` (dose, or dose / S for a normalised image) in fp32 and resist[...] = 1 where the
+// result reaches `threshold`, else 0.  `out` (the fp32 aerial image) may be NULL when only the contour mask is wanted.
+template <bool RESIST>
 __global__ void k_postprocess(const float* __restrict__ raw, int pn, int ns, int pW, int n_out, float rs,
-                              float* __restrict__ out)
+                              float* __restrict__ out, float gain, float threshold, unsigned char* __restrict__ resist)
 {
     const int ox = blockIdx.x * blockDim.x + threadIdx.x;
     const int oy = blockIdx.y;
@@ -253,7 +258,9 @@ __global__ void k_postprocess(const float* __restrict__ raw, int pn, int ns, int
     float v = 0.f;
     if (iy >= 0 && iy < ns && ix >= 0 && ix < ns)
         v = bilinear_at(raw + (size_t)p * pn * pn, pn, iy, ix, rs, ns == pn, true);
-    out[((size_t)p * n_out + oy) * n_out + ox] = v;
+    const size_t o = ((size_t)p * n_out + oy) * n_out + ox;
+    if (!RESIST || out) out[o] = v;
+    if constexpr (RESIST) resist[o] = (v * gain >= threshold) ? 1 : 0;
 }
 
 // bilinear up-scaling of the int16 mask geometry (mask.py:76-77) into a dense fp32 image
@@ -424,8 +431,26 @@ int litho_postprocess(const float* raw, int planes, int pn, double epsilon, floa
     const int ns = (int)std::floor((double)pn * scale);
     const int pW = (int)std::floor((pn - std::nearbyint(pn / epsilon)) / 2.0);
     const float rs = (float)(1.0 / scale);
-    hipLaunchKernelGGL(k_postprocess, dim3((n_out + 255) / 256, n_out, planes), dim3(256), 0, (hipStream_t)stream,
-                       raw, pn, ns, pW, n_out, rs, out);
+    hipLaunchKernelGGL(k_postprocess<false>, dim3((n_out + 255) / 256, n_out, planes), dim3(256), 0, (hipStream_t)stream,
+                       raw, pn, ns, pW, n_out, rs, out, 1.0f, 0.0f, (unsigned char*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return LITHO_OK;
+}
+
+int litho_postprocess_resist(const float* raw, int planes, int pn, double epsilon, double gain, double threshold,
+                             float* out, uint8_t* resist, void* stream)
+{
+    using namespace litho;
+    int n_out = 0;
+    int rc = litho_postprocess_size(pn, epsilon, &n_out);
+    if (rc) return rc;
+    if (!raw || !resist || planes < 1 || !(gain == gain) || !(threshold == threshold)) return LITHO_E_ARG;
+    const double scale = 1.0 / epsilon;
+    const int ns = (int)std::floor((double)pn * scale);
+    const int pW = (int)std::floor((pn - std::nearbyint(pn / epsilon)) / 2.0);
+    const float rs = (float)(1.0 / scale);
+    hipLaunchKernelGGL(k_postprocess<true>, dim3((n_out + 255) / 256, n_out, planes), dim3(256), 0, (hipStream_t)stream,
+                       raw, pn, ns, pW, n_out, rs, out, (float)gain, (float)threshold, (unsigned char*)resist);
     HIP_TRY(hipGetLastError());
     return LITHO_OK;
 }

@@ -108,6 +108,28 @@ def postProcess(raw, epsilon):
     return out
 
 
+def resistContour(raw, epsilon, threshold, dose=1.0, return_image=False):
+    """Constant-threshold resist model on the post-processed grid, fused into the post-process pass (the reference
+    lists photoresist response as an open goal, README.md:21; nothing to be compatible with): uint8 mask, 1 where
+    dose * image >= threshold.  `raw` is the accumulated intensity [pn,pn] or [planes,pn,pn] (abbeIntensity);
+    with return_image=True the fp32 aerial image of the same pass comes back too: (image, resist)."""
+    dev = nat.require_gpu(raw.device)
+    stacked = raw.dim() == 3
+    planes = raw.shape[0] if stacked else 1
+    pn = raw.shape[-1]
+    n_out = ctypes.c_int(0)
+    nat.check(nat.lib().litho_postprocess_size(pn, float(epsilon), ctypes.byref(n_out)), "litho_postprocess_size")
+    r = raw.to(torch.float32).contiguous()
+    shape = (planes, n_out.value, n_out.value) if stacked else (n_out.value, n_out.value)
+    resist = torch.empty(shape, dtype=torch.uint8, device=dev)
+    image = torch.empty(shape, dtype=torch.float32, device=dev) if return_image else None
+    with torch.cuda.device(dev):
+        nat.check(nat.lib().litho_postprocess_resist(nat.ptr(r), planes, pn, float(epsilon), float(dose), float(threshold),
+                                                     nat.ptr(image) if return_image else None, nat.ptr(resist),
+                                                     nat.stream_ptr(dev)), "litho_postprocess_resist")
+    return (image, resist) if return_image else resist
+
+
 def _all_reduce_sum(image, group):
     """ONE collective per image/stack.  RCCL ("nccl" backend on ROCm) reduces the device tensor in
     place over xGMI; a gloo group (CPU tests, or several ranks sharing one GPU) goes through a host copy."""

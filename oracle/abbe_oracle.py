@@ -2,8 +2,8 @@
 
 This file is the checker, never the product: only ``tests/``,
 ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
-it.  ``lithographysimulator_amd`` never does (tests/test_no_oracle_in_product.py
-enforces that).
+it.  ``lithographysimulator_amd`` never does (tests/test_host_logic_cpu.py,
+``test_product_never_touches_the_oracle``, enforces that).
 
 It is a restatement, in our own words, of what quarterwave0/LithographySimulator
 computes on its PyTorch-CPU path.  The arithmetic library the reference uses is

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (NA, PS, PUPIL_CASES, SOURCE_CASES, TOL_PHI, WL, f16, rel_max, sha256_packed, unpack_bitmap)
+from helpers import (NA, PS, PUPIL_CASES, SOURCE_CASES, TOL_IMAGE_MAX, TOL_PHI, WL, f16, rel_max, sha256_packed, unpack_bitmap)
 
 pytestmark = pytest.mark.gpu
 
@@ -190,3 +190,45 @@ def test_pupil_support_at_large_sizes(golden, L, dev, pn):
         assert [int(rows[0]), int(rows[-1]), int(cols[0]), int(cols[-1])] == list(g[f"box_{name}_{pn}"])
         sub = phi[::64, ::64].cpu()
         assert float((sub - torch.from_numpy(g[f"phisub_{name}_{pn}"])).abs().max()) < TOL_PHI
+
+
+@pytest.mark.parametrize("tag", ["demo64", "cfg1_bern", "cfg1_lines"])
+def test_resist_threshold_on_golden_images(golden, L, dev, tag):
+    """The constant-threshold resist model fused into the post-process pass (the reference's README lists photoresist
+    response as an open goal; the definition is ours): resist = (dose * image >= threshold) as uint8 -- a three-line
+    torch expression on the image of the same pass (exact), and on the REFERENCE's own final image (identical except
+    where an fp32 rounding of the resampling straddles the threshold)."""
+    g = golden("g5_images.npz")
+    raw = torch.from_numpy(g[f"{tag}_raw"]).to(dev)
+    ref_final = torch.from_numpy(g[f"{tag}_final"])
+    pn = raw.shape[0]
+    from oracle import abbe_oracle as O
+    eps, N = O.calculate_epsilon_n(4 / pn, PS, WL)
+    S = {"demo64": 184, "cfg1_bern": 3233, "cfg1_lines": 3233}[tag]
+    for dose, frac in ((1.0, 0.3), (0.7, 0.25), (1.0 / S, None)):
+        thr = (0.3 if frac is None else frac) * float(ref_final.max()) * (dose if frac is None else 1.0)
+        image, resist = L.resistContour(raw, eps, thr, dose=dose, return_image=True)
+        assert resist.dtype == torch.uint8 and resist.shape == image.shape == ref_final.shape
+        assert rel_max(image.cpu(), ref_final) < TOL_IMAGE_MAX                  # the image of the same pass is the post-processed one
+        expect = (image * torch.tensor(dose, dtype=torch.float32, device=dev) >= torch.tensor(thr, dtype=torch.float32, device=dev)).to(torch.uint8)
+        assert torch.equal(resist, expect)
+        only = L.resistContour(raw, eps, thr, dose=dose)                       # contour only: no image written
+        assert torch.equal(only, resist)
+        ref_mask = (ref_final * np.float32(dose) >= np.float32(thr)).to(torch.uint8)
+        flips = int((resist.cpu() != ref_mask).sum())
+        assert 0 < int(ref_mask.sum()) < ref_mask.numel() and flips <= max(2, ref_mask.numel() // 20000), (flips, int(ref_mask.sum()))
+
+
+def test_resist_threshold_stack_and_edges(L, dev):
+    """A 3-plane stack; threshold 0 (everything prints, the zero-padded border included), an unreachable threshold
+    (nothing prints), and a negative raw image (abs() is part of the post-process)."""
+    from oracle import abbe_oracle as O
+    pn = 256
+    eps, N = O.calculate_epsilon_n(4 / pn, PS, WL)
+    gen = torch.Generator().manual_seed(3)
+    raw = (torch.rand(3, pn, pn, generator=gen) * 5.0).to(dev)
+    img, res = L.resistContour(-raw, eps, 2.5, dose=1.0, return_image=True)
+    assert res.shape == img.shape == (3, pn, pn)
+    assert torch.equal(res, (img >= 2.5).to(torch.uint8)) and rel_max(img.cpu(), torch.stack([O.post_process(r.cpu(), eps) for r in raw])) < 1e-6
+    assert int(L.resistContour(raw, eps, 0.0).sum()) == 3 * pn * pn
+    assert int(L.resistContour(raw, eps, 1e30).sum()) == 0

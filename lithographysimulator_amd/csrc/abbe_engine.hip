@@ -369,7 +369,7 @@ static int env_int(const char* name, int dflt)
 
 // Tuning / test knobs.  Read ONCE per C-ABI call (the parity tests flip them between calls), never per launch.
 struct Knobs {
-    int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk, xsplit, rect, xrect, coarse;
+    int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk, xsplit, rect, xrect, coarse, gcombine;
     static Knobs read()
     {
         Knobs k;
@@ -387,6 +387,7 @@ struct Knobs {
         k.rect = env_int("LITHO_ABBE_RECT", 1);
         k.xrect = env_int("LITHO_ABBE_XRECT", 1);
         k.coarse = env_int("LITHO_ABBE_COARSE", 1);
+        k.gcombine = env_int("LITHO_ABBE_GCOMBINE", 1);
         return k;
     }
 };
@@ -459,7 +460,7 @@ static void make_geom(PassGeom& g, int pn, int N, int r0, int c0, int h, int wdt
     g.pn = pn; g.c = pn / 2; g.N = N; g.nt = (pn + 3) / 4;
     g.kx0 = c0 - g.c; g.kx1 = c0 + wdt - g.c;
     g.ky0 = r0 - g.c; g.ky1 = r0 + h - g.c;
-    g.rows = h; g.general = general; g.rect_off = 0;
+    g.rows = h; g.general = general; g.rect_off = 0; g.gcombine = 0;
     g.xmask = slot_mask(N, g.kx0, g.kx1);
     g.ymask = slot_mask(N, g.ky0, g.ky1);
     set_tile(g, h, tile_cols);
@@ -535,6 +536,7 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
     // k_ypass_rect: 4096 / N adjacent columns per wave (they must fit one T tile)
     const bool rect = (variant == 0 ? N <= 2048 : rect_ok && N <= 2048) && ((4096 / N) <= tc || (N == 256 && tc == 8));
     g.rect_off = rect ? 0 : 1;
+    g.gcombine = kn.gcombine ? 1 : 0;
     const bool wave_y = w64_shape && (g.tcl == 2 || g.tcl == 3) && ((N != 512 && N != 256) || rect) &&
                         (variant == 1 || rect || N == 4096);
 
@@ -709,7 +711,7 @@ static int reconstruct_plane(const SizeOps* ops, const SizeOps* ops_c, const Wor
     PassGeom gf;
     gf.pn = pn; gf.c = pn / 2; gf.N = pn; gf.nt = (pn + 3) / 4;
     gf.kx0 = -pn / 2; gf.kx1 = pn / 2; gf.ky0 = gf.kx0; gf.ky1 = gf.kx1;
-    gf.rows = pn; gf.general = 0; gf.rect_off = 0;
+    gf.rows = pn; gf.general = 0; gf.rect_off = 0; gf.gcombine = 0;
     gf.xmask = slot_mask(pn, gf.kx0, gf.kx1); gf.ymask = gf.xmask;
     set_tile(gf, gf.rows);
     RealImageLoader ldr{ic, pn, 0, nullptr};
@@ -895,7 +897,7 @@ static int mask_spectrum(const int16_t* geo, int pn, double eps, int N, float2* 
     g.pn = pn; g.c = pn / 2; g.N = N; g.nt = (int)nt;
     g.kx0 = j0 - N / 2; g.kx1 = j1 - N / 2;
     g.ky0 = g.kx0; g.ky1 = g.kx1;
-    g.rows = j1 - j0; g.general = 0; g.rect_off = 0;
+    g.rows = j1 - j0; g.general = 0; g.rect_off = 0; g.gcombine = 0;
     g.xmask = slot_mask(N, g.kx0, g.kx1);
     g.ymask = slot_mask(N, g.ky0, g.ky1);
     set_tile(g, g.rows);

@@ -28,6 +28,8 @@ struct PassGeom {
     int rows;               // number of T rows (= ky1 - ky0)
     int general;            // 1: roll stays on P, modular gather (wrapping shifts)
     int rect_off;           // 1: N = 2048 y-pass by the S = 32 wave kernel instead of k_ypass_rect (test knob)
+    int gcombine;           // 1: k_ypass_rect puts the two groups of a column block into ONE workgroup and combines their
+                            //    accumulators through LDS before the slab flush (half the flush traffic)
     unsigned xmask, ymask;  // bit e set: slot e can be non-zero for SOME thread (x / y input)
     long long t_point;      // float2 elements of T per source point = ceil(pn/tc)*rows*tc
 };

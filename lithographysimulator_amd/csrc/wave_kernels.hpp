@@ -281,11 +281,18 @@ __global__ __launch_bounds__(256, 2) void k_ypass_pair(
 // pn x pn grid q = 2 v that spans the whole period (E_s(2v) = sum_k A_s[k] w_pn^(k v)): every bin is kept
 // (64 accumulators per lane) and |k| <= pn/4 = N/4 of the inputs are live; abbe_engine.hip reconstructs the fine
 // image from it (band-limited interpolation + the exact Nyquist-line correction).
-template <int LOG2N, int TC, bool FULL = false>
-__global__ __launch_bounds__(256, 2) void k_ypass_rect(
+// GW = groups per workgroup.  GW = 1: blockIdx.y = plane * G + group, every group flushes into its own slab.  GW = 2:
+// a 512-thread workgroup holds BOTH groups of its column block (waves 0-3: group 2 gb, waves 4-7: group 2 gb + 1;
+// blockIdx.y = plane * G/2 + gb); at the end the odd group hands its accumulators to the even one through its
+// transpose matrix (64 x 64 floats fit), which adds them and flushes ONE slab (index gb): the read-modify-write of
+// the slabs -- 67 MB per 12-item launch at 2048^2 against 201 MB of T -- is halved, at the same residency (8 waves
+// per CU).
+template <int LOG2N, int TC, bool FULL = false, int GW = 1>
+__global__ __launch_bounds__(256 * GW, 2) void k_ypass_rect(
     const float2* __restrict__ Tbuf, float* __restrict__ slab, const float2* __restrict__ twtab,
     PassGeom g, int nb, int G, int gstride)
 {
+    static_assert(GW == 1 || GW == 2, "one or two groups per workgroup");
     static_assert(LOG2N >= 8 && LOG2N <= 11, "multi-column-per-wave y-pass: N = 256 (full output only), 512, 1024, 2048");
     static_assert(TC == 2 || TC == 4 || TC == 8, "T tiles are 2, 4 or 8 columns wide");
     static_assert(LOG2N >= 9 || FULL, "N = 256: the coarse-grid transform of 256^2 images");
@@ -301,13 +308,16 @@ __global__ __launch_bounds__(256, 2) void k_ypass_rect(
     float* smem = reinterpret_cast<float*>(smem_raw);
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cw = wv & 3, gl = wv >> 2;                                 // column wave, group inside the workgroup
     float* lds = smem + wv * W::LDS_FLOATS;
     typename W::LaneTwiddles tw;
     W::load_lane_twiddles(tw, twtab, lane, 1);
 
-    const int qx0 = wave_first_column<TC, 4 * NL>(blockIdx.x) + NL * wv;  // multiple of NL: the wave's columns sit in one tile
+    const int qx0 = wave_first_column<TC, 4 * NL>(blockIdx.x) + NL * cw;  // multiple of NL: the wave's columns sit in one tile
     const int tile = qx0 / TC, col = qx0 & (TC - 1);
-    const int plane = blockIdx.y / G, grp = blockIdx.y - plane * G;      // see k_ypass_acc
+    const int GB = G / GW;                                               // group blocks (= slabs written) per plane
+    const int plane = blockIdx.y / GB, gb = blockIdx.y - plane * GB;     // see k_ypass_acc
+    const int grp = gb * GW + gl;
     Tbuf += (size_t)plane * nb * g.t_point;
     slab += (size_t)plane * gstride * g.nt * 4 * g.pn;
     const bool active = tile * TC < g.pn;
@@ -350,9 +360,17 @@ __global__ __launch_bounds__(256, 2) void k_ypass_rect(
         });
     }
 
+    if constexpr (GW == 2) {
+        // the odd group's accumulators -> its own (now idle) transpose matrix, [i][lane]; the even group adds them
+        if (gl == 1) static_for<0, NACC>([&](auto i_) { constexpr int i = decltype(i_)::value; lds[i * 64 + lane] = acc[i]; });
+        __syncthreads();
+        if (gl == 1) return;
+        const float* other = smem + (wv + 4) * W::LDS_FLOATS;
+        static_for<0, NACC>([&](auto i_) { constexpr int i = decltype(i_)::value; acc[i] += other[i * 64 + lane]; });
+    }
     const int qx = qx0 + lane / H, m = lane & (H - 1);
     if (!active || qx >= g.pn) return;
-    float* srow = slab + ((size_t)grp * g.nt * 4 + qx) * g.pn;
+    float* srow = slab + ((size_t)gb * g.nt * 4 + qx) * g.pn;
     static_for<0, NACC>([&](auto i_) {
         constexpr int i = decltype(i_)::value;
         constexpr int k2 = kept_k2(i);
@@ -490,14 +508,24 @@ static hipError_t launch_ypass_wave_tc(const float2* T, float* slab, const float
         } else if constexpr (LOG2N >= 8 && LOG2N <= 11) {
             constexpr int NL = 4096 >> LOG2N;
             if constexpr (NL <= TC || NL == 2 * TC) {
+                if (g.gcombine && G % 2 == 0) {             // both groups of a column block in one 512-thread workgroup
+                    static LdsOnce once2;
+                    auto kern2 = k_ypass_rect<LOG2N, TC, true, 2>;
+                    hipError_t e2 = set_lds(once2, kern2, 2 * lds4);
+                    if (e2 != hipSuccess) return e2;
+                    hipLaunchKernelGGL(kern2, dim3(wave_grid_x<TC, 4 * NL>(g.pn), planes * (G / 2)), dim3(512), 2 * lds4, st,
+                                       T, slab, tw, g, nb, G, gstride);
+                    note_kernel(1, "k_ypass_rect<%d, %d, true, 2>", LOG2N, TC);
+                    return hipGetLastError();
+                }
                 static LdsOnce once;
                 auto kern = k_ypass_rect<LOG2N, TC, true>;
                 hipError_t e = set_lds(once, kern, lds4);
                 if (e != hipSuccess) return e;
                 hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, 4 * NL>(g.pn), planes * G), dim3(256), lds4, st, T, slab, tw,
                                    g, nb, G, gstride);
-                note_kernel(1, "k_ypass_rect<%d, %d, true>", LOG2N, TC);
-            return hipGetLastError();
+                note_kernel(1, "k_ypass_rect<%d, %d, true, 1>", LOG2N, TC);
+                return hipGetLastError();
             }
         }
         return hipErrorNotSupported;
@@ -515,14 +543,24 @@ static hipError_t launch_ypass_wave_tc(const float2* T, float* slab, const float
         constexpr int NL = 4096 >> LOG2N;                       // columns per wave of k_ypass_rect
         if constexpr (NL <= TC) {
             if (!g.rect_off) {
+                if (g.gcombine && G % 2 == 0) {
+                    static LdsOnce once2;
+                    auto kern2 = k_ypass_rect<LOG2N, TC, false, 2>;
+                    hipError_t e2 = set_lds(once2, kern2, 2 * lds4);
+                    if (e2 != hipSuccess) return e2;
+                    hipLaunchKernelGGL(kern2, dim3(wave_grid_x<TC, 4 * NL>(g.pn), planes * (G / 2)), dim3(512), 2 * lds4, st,
+                                       T, slab, tw, g, nb, G, gstride);
+                    note_kernel(1, "k_ypass_rect<%d, %d, false, 2>", LOG2N, TC);
+                    return hipGetLastError();
+                }
                 static LdsOnce once;
                 auto kern = k_ypass_rect<LOG2N, TC>;
                 hipError_t e = set_lds(once, kern, lds4);
                 if (e != hipSuccess) return e;
                 hipLaunchKernelGGL(kern, dim3(wave_grid_x<TC, 4 * NL>(g.pn), planes * G), dim3(256), lds4, st, T, slab, tw,
                                    g, nb, G, gstride);
-                note_kernel(1, "k_ypass_rect<%d, %d, false>", LOG2N, TC);
-            return hipGetLastError();
+                note_kernel(1, "k_ypass_rect<%d, %d, false, 1>", LOG2N, TC);
+                return hipGetLastError();
             }
         }
         if constexpr (LOG2N >= 10) {

@@ -296,6 +296,7 @@ static int g_cap(int pn)
 }
 static constexpr int SLAB_FLUSH_BATCHES = 64;
 static constexpr size_t T_BUDGET_MAX = (size_t)1 << 30;
+static constexpr size_t T_BUDGET_BIG = (size_t)4 << 30;      // images whose T items cannot be batched inside the Infinity Cache (pn >= 4096)
 static constexpr size_t T_BUDGET_MIN = (size_t)256 << 20;
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -306,7 +307,11 @@ static size_t t_budget(int pn)
     const size_t one_general = nt * (size_t)pn * 4 * sizeof(float2);
     size_t b = 64 * one_general;
     if (b < T_BUDGET_MIN) b = T_BUDGET_MIN;                  // small images: room for batches of several points per y-pass group
-    if (b > T_BUDGET_MAX) b = T_BUDGET_MAX;
+    // pn >= 4096: a T item is 67 MB and more, T streams through HBM whatever the batch, and longer batches amortise the
+    // y-pass's accumulator flush and ramp (4096^2, us per source point: 15 items 45.3, 30 44.1, 45 43.5, 60 43.2) --
+    // 4 GiB of a 288 GB device.
+    const size_t cap = pn >= 4096 ? T_BUDGET_BIG : T_BUDGET_MAX;
+    if (b > cap) b = cap;
     if (b < one_general + one_general / 2) b = one_general + one_general / 2;
     return b;
 }
@@ -579,11 +584,12 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
     int64_t items = items_ws;
     int64_t items_cache = (int64_t)(((size_t)208 << 20) / item_bytes);
     // 4096^2 (67 MB per item): not even 8 items fit the cache, T round-trips HBM whatever the batch -- then the batch
-    // is as long as the workspace allows (15 items: fewer accumulator flushes in the y-pass) and an x-pass workgroup
-    // walks the WHOLE batch for its row (one prologue per row).  us per source point, coarse-grid path, alternating
-    // A/B: 8 items x chunks of 4 49.9 / 49.8; 12 x 6 47.9; 12 x 12 45.6; 15 x 5 47.5; 15 x 15 45.3 / 45.2.
+    // is as long as the workspace allows (60 items of its 4 GiB: fewer accumulator flushes in the y-pass) and an x-pass
+    // workgroup walks 15 items for its row.  us per source point, coarse-grid path, alternating A/B (round 2, 1 GiB):
+    // 8 items x chunks of 4 49.9 / 49.8; 12 x 6 47.9; 12 x 12 45.6; 15 x 5 47.5; 15 x 15 45.3 / 45.2; round 3 (4 GiB):
+    // 30 x 15 44.1, 45 x 15 43.5, 60 x 15 43.2, 60 x 60 43.3.
     const bool beyond_cache = items_cache < 8;
-    if (beyond_cache) items_cache = 16;
+    if (beyond_cache) items_cache = 60;
     if (items > items_cache) items = items_cache;
     if (PC > items_ws) PC = (int)items_ws;
     int G = Gtot / PC;                                         // groups per plane
@@ -608,7 +614,10 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
         xchunk = want;
         if (want == 4) for (int cand : {4, 5, 3, 6, 2}) if (bs % cand == 0) { xchunk = cand; break; }
         if (want == 2) for (int cand : {2, 3, 1}) if (bs % cand == 0) { xchunk = cand; break; }
-        if (beyond_cache && PC == 1) xchunk = (int)bs;         // see above
+        if (beyond_cache && PC == 1) {                         // see above
+            xchunk = (int)bs;
+            for (int cand : {15, 12, 16, 10, 20, 8, 6}) if (bs > cand && bs % cand == 0) { xchunk = cand; break; }
+        }
         // 1024-point rows (64-thread workgroups, 16 per CU): longer chunks pay -- coarse-grid x-pass at 1024^2,
         // us per point: chunk 2 1.40, 3 1.27, 4 1.18, 6 1.12, 8 1.20, 12 1.03, 16 1.06, 24 1.34, 48 2.0
         if (N == 1024 && variant == 0 && PC == 1) for (int cand : {12, 16, 8, 6}) if (bs % cand == 0) { xchunk = cand; break; }

@@ -7,11 +7,11 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R
 mkdir -p $O
 python3 bench.py > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 bench.py --no-cpu-baseline --no-extra > $O/bench_under_rocprof.json 2> $O/rocprof.err
+# (configs 1, 2, 4-shard and 5 ride in bench.json's extra_workloads since round 3; their own full lines with roofline:)
 python3 bench.py --workload cfg1 > $O/bench_cfg1.json 2>/dev/null
 python3 bench.py --workload cfg2 > $O/bench_cfg2.json 2>/dev/null
 python3 bench.py --workload cfg4 --shard 0/8 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_cfg4_shard0of8.json 2>/dev/null
-python3 bench.py --workload cfg5 --steps 1 --warmup 0 --no-cpu-baseline > $O/bench_cfg5.json 2>/dev/null
 # SKIP_PMC=1: bench lines and kernel stats only (e.g. after profiles/traffic.json has been refreshed from the PMC passes)
 [ -n "$SKIP_PMC" ] || bash scripts/pmc_traffic.sh $R cfg3 504 cfg2 2016 cfg4 64 cfg5 120 cfg1 3233
 # keep the summaries small: the raw per-dispatch CSVs stay in gpurun_out

@@ -426,6 +426,34 @@ int main(int argc, char** argv)
         printf("same kernel, 2-column tiles: %8.2f us per launch (%.3f x product)\n", t2, t2 / t_ref);
     }
 #endif
+#ifdef LAB_SLAB4096
+    {   // would column slabs help the 4096-point y-pass?  The first 1024 columns of a 12-item batch (16.8 MB per item: the
+        // slab's T), read (a) cache-resident, launches back to back, (b) after a 1 GiB fill has evicted it (= from HBM)
+        static_assert(L2N == 12, "LAB_SLAB4096 needs -DL2N=12");
+        constexpr size_t ldsf = 4 * WaveSq<6>::LDS_FLOATS * sizeof(float) + (size_t)WaveSq<6>::TW_LDS_FLOAT2 * sizeof(float2);
+        auto kern = k_ypass_wave<12, 8, true>;
+        CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf));
+        float* big; CK(hipMalloc(&big, (size_t)1 << 30));
+        hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+        for (int cols : {1024, 4096}) {
+            const dim3 grid(cols / 4, G);
+            for (int evict = 0; evict < 2; ++evict) {
+                double best = 1e30;
+                for (int r = 0; r < 6; ++r) {
+                    if (evict) CK(hipMemsetAsync(big, r, (size_t)1 << 30, 0));
+                    CK(hipEventRecord(a));
+                    hipLaunchKernelGGL(kern, grid, dim3(256), ldsf, 0, T, slab, tw, g, nb, G, G);
+                    CK(hipEventRecord(b));
+                    CK(hipEventSynchronize(b));
+                    float ms; CK(hipEventElapsedTime(&ms, a, b));
+                    if (r > 0 && ms * 1e3 < best) best = ms * 1e3;
+                }
+                printf("k_ypass_wave<12,8,true>, %4d columns x %d items, T %s: %8.2f us per launch = %.3f us per item per 1024 columns\n",
+                       cols, nb, evict ? "evicted (HBM)" : "cache-resident if it fits", best, best / nb / (cols / 1024));
+            }
+        }
+    }
+#endif
 #ifdef LAB_PF
     {   // k_ypass_rect with LDS-DMA prefetch of the next item
         using PF = RectPrefetch<L2N, true>;

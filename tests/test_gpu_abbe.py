@@ -487,6 +487,7 @@ def test_consecutive_shard_4096_vs_golden(golden, L, dev, monkeypatch, path):
     g = golden("g12_shard4096.npz")
     pn = 4096
     monkeypatch.setenv("LITHO_ABBE_COARSE", "2" if path == "coarse" else "0")
+    monkeypatch.setenv("LITHO_ABBE_BATCH", "12")               # 64 points = 5 full batches + a ragged one (the default batch is 60 here)
     lo, hi, S = (int(v) for v in g["cfg4shard_range"])
     mask = L.Mask(bernoulli_mask(pn), PS, dev)
     mft = mask.fraunhofer(WL, True)

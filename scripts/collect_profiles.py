@@ -1,0 +1,32 @@
+"""Copy the summaries of a profile round from gpurun_out/<round>/ (scratch) into profiles/ (tracked):
+    python scripts/collect_profiles.py r03
+bench lines, the rocprofv3 kernel stats of the default command, the PMC summaries, and profiles/traffic.json
+(merged from the per-workload traffic_*.json of scripts/pmc_traffic.sh)."""
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = sys.argv[1]
+src = os.path.join(ROOT, "gpurun_out", R)
+dst = os.path.join(ROOT, "profiles")
+pairs = [("bench.json", f"{R}_bench.json"), ("bench_under_rocprof.json", f"{R}_bench_under_rocprof.json"),
+         ("stats/bench_kernel_stats.csv", f"{R}_bench_kernel_stats.csv"), ("bench_cfg1.json", f"{R}_bench_cfg1.json"),
+         ("bench_cfg2.json", f"{R}_bench_cfg2.json"), ("bench_cfg4_shard0of8.json", f"{R}_bench_cfg4_shard0of8.json")]
+pairs += [(os.path.basename(p), f"{R}_" + os.path.basename(p)) for p in glob.glob(os.path.join(src, "pmc_cfg*_summary.txt"))]
+for a, b in pairs:
+    pa = os.path.join(src, a)
+    if os.path.exists(pa) and os.path.getsize(pa) > 0:
+        shutil.copy(pa, os.path.join(dst, b))
+        print("copied", b)
+traffic = {}
+for p in sorted(glob.glob(os.path.join(src, "traffic_cfg*.json"))):
+    try:
+        traffic.update(json.load(open(p)))
+    except Exception as exc:
+        print("skipped", p, exc)
+if traffic:
+    json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+    print("traffic.json:", {k: (round(v["xpass_bytes_per_item"] / 1e6, 2), round(v["ypass_bytes_per_item"] / 1e6, 2)) for k, v in traffic.items()})

@@ -142,12 +142,13 @@ class Workload:
         self.dev = dev
         torch.cuda.synchronize()
 
-    def step(self, lo=0, hi=None, group=None):
+    def step(self, lo=0, hi=None, group=None, plan_cache=None):
         """One complete image: the whole source list through abbeImage, or the slice [lo, hi) through the three calls
         abbeImage makes per rank."""
         import lithographysimulator_amd as L
         if hi is None or (lo, hi) == (0, self.S_full):
-            return L.abbeImage(self.mask, self.maskFT, self.pupil, self.bitmap, PS, self.mask.deltaK, WL, True, self.dev, group=group)
+            return L.abbeImage(self.mask, self.maskFT, self.pupil, self.bitmap, PS, self.mask.deltaK, WL, True, self.dev, group=group,
+                               plan_cache=plan_cache)
         sh = L.sourceShifts(self.bitmap, self.pn)[lo:hi]
         return L.postProcess(L.abbeIntensity(self.maskFT, self.pupil, sh, self.N), self.epsilon)
 
@@ -236,6 +237,19 @@ def extra_workload(torch, nat, dev, name, shard=None, steps=1, warm_points=0, pr
            "kernels": {k: {"kernel": v["kernel"], "avg_launch_ms": v["avg_launch_ms"], "items_per_launch": v["items_per_launch"]}
                        for k, v in kern.items()},
            "profile_sample": f"first {sh.shape[0]} consecutive source points" + (" x 2 planes" if w.planes > 1 else "")}
+    if name == "cfg1":
+        # the same image as one of a SEQUENCE sharing pupil and source (PlanCache: no compaction, no planning launches, no
+        # host wait from the second call on), 100 images back to back
+        cache = L.PlanCache()
+        for _ in range(3):
+            w.step(plan_cache=cache)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            image = w.step(plan_cache=cache)
+        torch.cuda.synchronize()
+        t_seq = (time.perf_counter() - t0) / 100
+        out["sequence_with_plan_cache"] = {"images": 100, "ms_per_image": t_seq * 1e3, "value": units / t_seq}
     del w, image
     torch.cuda.empty_cache()
     return out

@@ -105,6 +105,23 @@ int litho_abbe_accumulate_counted(const void *maskFT, const void *pupil, int pla
                                   int pn, int N, float *out, void *workspace, size_t workspace_bytes,
                                   void *stream, int64_t *count_host);
 
+/* ---- Plan reuse for sequences of images that share the pupil (stack) and the source list -- many masks through one
+ * optical setting.  The two calls above read 56 bytes back to plan EVERY call (pupil support box, shift extents, count).
+ * With a caller-held record the first call plans as usual and fills it; later calls with the same record issue no
+ * planning launch and never wait for the stream (images can be queued back to back).  CONTRACT: the caller passes a
+ * valid record only while `pupil`, `shifts` and the count are unchanged (set plan->valid = 0 after changing them); pn, N
+ * and planes are checked.  count_dev may be NULL (then `capacity` is the number of source points, as in
+ * litho_abbe_accumulate).  litho_abbe_last_plan field [15] = 1 when the call planned from the record. */
+typedef struct litho_abbe_plan {
+    int32_t words[16];      /* the read-back plan words (the library's business; [8] = source-point count) */
+    int32_t valid;          /* 0: empty, the call fills it; 1: use it */
+    int32_t pn, N, planes;  /* what it was made for */
+} litho_abbe_plan;
+int litho_abbe_accumulate_planned(const void *maskFT, const void *pupil, int planes,
+                                  const int32_t *shifts, const int32_t *count_dev, int64_t capacity,
+                                  int pn, int N, float *out, void *workspace, size_t workspace_bytes,
+                                  void *stream, litho_abbe_plan *plan, int64_t *count_host);
+
 /* ---- Single-point field: calculateFFTAerial(pf, maskFFFT, pixelNumber, N)
  * (imageformation.py:32-45).  field = complex64 [pn,pn].  Reads back 16 bytes. */
 int litho_abbe_field(const void *pf, const void *maskFT, int pn, int N, void *field,
@@ -138,7 +155,8 @@ int litho_mask_spectrum(const int16_t *geometry, int pn, double epsilon, int N, 
  * [11]=x-pass kernel family (1 plane-fused k_xpass_abbe, 2 k_xpass_split, 3 k_xpass_rect, 0 fall-backs),
  * [12]=1 when the coarse-grid path ran (pn-point transforms on the grid q = 2 v, fine image reconstructed once
  * per plane), [13]=1 when the y-pass ran a wave-level kernel (k_ypass_rect / k_ypass_wave / k_ypass_pair), [14]=1 when
- * the pupil's support box lies inside the natural support |k| <= pn/4, [15] reserved. */
+ * the pupil's support box lies inside the natural support |k| <= pn/4, [15]=1 when the call planned from a caller-held
+ * record (litho_abbe_accumulate_planned). */
 int litho_abbe_last_plan(int64_t fields_host[16]);
 
 /* Names of the x-pass and y-pass kernels the last litho_abbe_accumulate on this thread launched in its source-point

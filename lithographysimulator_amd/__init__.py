@@ -1,11 +1,12 @@
 """MI355X-native Abbe aerial-image engine behind the object API of
 quarterwave0/LithographySimulator (Mask / LightSource / Pupil / abbeImage)."""
-from .imageformation import abbeImage, abbeIntensity, calculateFFTAerial, postProcess, resistContour   # noqa: F401
+from .imageformation import (PlanCache, abbeImage, abbeIntensity, calculateFFTAerial, postProcess,   # noqa: F401
+                             resistContour)
 from .lightsource import LightSource, sourceShifts, sourceShiftsAsync                                      # noqa: F401
 from .mask import Mask                                                                  # noqa: F401
 from .pupil import (OSAindexToMN, Pupil, generatePhi, generateWavefrontError,           # noqa: F401
                     generateZ, throughFocusPupils)
 
-__all__ = ["Mask", "LightSource", "Pupil", "abbeImage", "abbeIntensity", "calculateFFTAerial", "postProcess", "resistContour",
+__all__ = ["Mask", "LightSource", "Pupil", "abbeImage", "abbeIntensity", "calculateFFTAerial", "postProcess", "resistContour", "PlanCache",
            "sourceShifts", "sourceShiftsAsync", "OSAindexToMN", "generateWavefrontError", "generatePhi", "generateZ",
            "throughFocusPupils"]

@@ -29,6 +29,8 @@ _SIGNATURES = {
                                       c_void_p, c_size_t, c_void_p]),
     "litho_abbe_accumulate_counted": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int,
                                               c_void_p, c_void_p, c_size_t, c_void_p, POINTER(c_int64)]),
+    "litho_abbe_accumulate_planned": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                              c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, POINTER(c_int64)]),
     "litho_abbe_field": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "litho_postprocess_size": (c_int, [c_int, c_double, POINTER(c_int)]),
     "litho_postprocess": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p]),
@@ -138,11 +140,18 @@ def epsilon_n(deltaK, pixelSize, wavelength):
     return eps.value, N.value
 
 
+class PlanRecord(ctypes.Structure):
+    """litho_abbe_plan (include/litho_abbe.h)."""
+    _fields_ = [("words", ctypes.c_int32 * 16), ("valid", ctypes.c_int32), ("pn", ctypes.c_int32),
+                ("N", ctypes.c_int32), ("planes", ctypes.c_int32)]
+
+
 def last_plan():
     arr = (c_int64 * 16)()
     lib().litho_abbe_last_plan(arr)
     keys = ("general", "box_row0", "box_col0", "box_rows", "box_cols", "batch", "launches", "variant",
-            "planes_in_flight", "groups_per_plane", "xchunk", "fused_xpass", "coarse_grid", "wave_ypass", "natural_box")
+            "planes_in_flight", "groups_per_plane", "xchunk", "fused_xpass", "coarse_grid", "wave_ypass", "natural_box",
+            "planned_from_record")
     return dict(zip(keys, list(arr)))
 
 

@@ -744,9 +744,11 @@ static int reconstruct_plane(const SizeOps* ops, const SizeOps* ops_c, const Wor
     return LITHO_OK;
 }
 
+// `reuse`: optional caller-held plan record (litho_abbe_plan).  Valid and matching (pn, N, planes): its words are used, no
+// planning kernel is launched and the call never waits for the stream; otherwise the plan is made as usual and recorded.
 static int abbe_accumulate(const float2* M, const float2* P, int planes, const int* shifts, int64_t S,
                            const int* count_dev, int64_t* count_out, int pn, int N, float* out, void* ws,
-                           size_t ws_bytes, hipStream_t st)
+                           size_t ws_bytes, hipStream_t st, litho_abbe_plan* reuse = nullptr)
 {
     int rc = check_sizes(pn, N);
     if (rc) return rc;
@@ -760,14 +762,25 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     const Knobs kn = Knobs::read();
 
     hipLaunchKernelGGL(k_twiddle_table, dim3((N + 255) / 256), dim3(256), 0, st, w.twtab, N);
-    hipLaunchKernelGGL(k_plan_init, dim3(1), dim3(64), 0, st, w.plan);
-    hipLaunchKernelGGL(k_pupil_box, dim3((pn + BOX_ROWS_PER_BLOCK - 1) / BOX_ROWS_PER_BLOCK, planes), dim3(256), 0, st,
-                       P, pn, w.plan);
-    hipLaunchKernelGGL(k_shift_extents, dim3(256), dim3(256), 0, st, shifts, (long long)S, count_dev, w.plan);
-    HIP_TRY(hipGetLastError());
     int pl[PLAN_WORDS];
-    rc = read_plan(w, pl, st);                               // the ONE host wait of the image path
-    if (rc) return rc;
+    const bool from_record = reuse && reuse->valid == 1 && reuse->pn == pn && reuse->N == N && reuse->planes == planes &&
+                             reuse->words[8] <= S;
+    if (from_record) {
+        for (int i = 0; i < PLAN_WORDS; ++i) pl[i] = reuse->words[i];
+    } else {
+        hipLaunchKernelGGL(k_plan_init, dim3(1), dim3(64), 0, st, w.plan);
+        hipLaunchKernelGGL(k_pupil_box, dim3((pn + BOX_ROWS_PER_BLOCK - 1) / BOX_ROWS_PER_BLOCK, planes), dim3(256), 0, st,
+                           P, pn, w.plan);
+        hipLaunchKernelGGL(k_shift_extents, dim3(256), dim3(256), 0, st, shifts, (long long)S, count_dev, w.plan);
+        HIP_TRY(hipGetLastError());
+        rc = read_plan(w, pl, st);                           // the ONE host wait of the image path
+        if (rc) return rc;
+        if (reuse) {
+            for (int i = 0; i < 16; ++i) reuse->words[i] = i < PLAN_WORDS ? pl[i] : 0;
+            reuse->pn = pn; reuse->N = N; reuse->planes = planes; reuse->valid = 1;
+        }
+    }
+    g_last_plan[15] = from_record ? 1 : 0;
     S = pl[8];                                               // = S, or the device-side count of the source list
     if (count_out) *count_out = S;
     if (S == 0 || pl[1] < pl[0]) return LITHO_OK;            // no source point / pupil identically zero: nothing to add
@@ -948,6 +961,16 @@ int litho_abbe_accumulate_counted(const void* maskFT, const void* pupil, int pla
     if (!count_dev) return LITHO_E_ARG;
     return litho::abbe_accumulate((const float2*)maskFT, (const float2*)pupil, planes, shifts, capacity, count_dev,
                                   count_host, pn, N, out, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int litho_abbe_accumulate_planned(const void* maskFT, const void* pupil, int planes, const int32_t* shifts,
+                                  const int32_t* count_dev, int64_t capacity, int pn, int N, float* out,
+                                  void* workspace, size_t workspace_bytes, void* stream, litho_abbe_plan* plan,
+                                  int64_t* count_host)
+{
+    if (!plan) return LITHO_E_ARG;
+    return litho::abbe_accumulate((const float2*)maskFT, (const float2*)pupil, planes, shifts, capacity, count_dev,
+                                  count_host, pn, N, out, workspace, workspace_bytes, (hipStream_t)stream, plan);
 }
 
 int litho_abbe_field(const void* pf, const void* maskFT, int pn, int N, void* field, void* workspace,

@@ -45,13 +45,36 @@ def calculateFFTAerial(pf, maskFFFT, pixelNumber, N):
     return out
 
 
-def abbeIntensity(maskFT, pupilF, shifts, N, out=None, count=None):
+class PlanCache:
+    """Caller-held plan for SEQUENCES of images that share the pupil (stack) and the source -- many masks through one
+    optical setting.  Every abbeImage / abbeIntensity call otherwise compacts the source bitmap and reads 56 bytes back
+    to plan (pupil support box, shift extents, count): one host wait per image.  With a PlanCache the first call does
+    that and records it; later calls with the SAME cache issue no compaction, no planning launch and never wait for the
+    stream, so images queue back to back.  Contract: reuse a cache only while the pupil tensor(s) and the source bitmap
+    are unchanged -- call invalidate() (or make a new one) after changing either; sizes are checked."""
+
+    def __init__(self):
+        self.record = nat.PlanRecord()
+        self.shifts = None          # compacted (dy,dx) list of the source bitmap (abbeImage)
+        self.count = None           # its device-side count, until the first call has brought it to the host
+        self.S = None
+
+    def invalidate(self):
+        self.record.valid = 0
+        self.shifts = self.count = self.S = None
+
+    @property
+    def valid(self):
+        return bool(self.record.valid)
+
+
+def abbeIntensity(maskFT, pupilF, shifts, N, out=None, count=None, plan=None):
     """The loop of abbeImage (imageformation.py:54-67) for an explicit (dy,dx) list:
     returns / accumulates into the raw fp32 intensity [planes?,pn,pn] BEFORE post-processing.
     pupilF may be [pn,pn] or a through-focus stack [planes,pn,pn].
     `count`: optional 1-element int32 DEVICE tensor holding the number of valid rows of `shifts`
     (sourceShiftsAsync); the call then returns (intensity, S) and the whole image path waits for the
-    stream once."""
+    stream once.  `plan`: optional PlanCache (see there); the call then returns (intensity, S) as well."""
     pn = _square(maskFT, "maskFT")
     if pupilF.dim() not in (2, 3) or tuple(pupilF.shape[-2:]) != (pn, pn) or (pupilF.dim() == 3 and pupilF.shape[0] < 1):
         # e.g. a default Pupil() (pixelNumber 64) with a 256^2 mask: the reference fails at pf * maskFFFT
@@ -76,9 +99,17 @@ def abbeIntensity(maskFT, pupilF, shifts, N, out=None, count=None):
     nat.check(rc, "abbeImage")
     ws = nat.workspace(dev, pn, int(N))
     with torch.cuda.device(dev):
+        if count is not None and (count.dtype != torch.int32 or count.numel() != 1 or count.device != m.device):
+            raise ShapeError("count must be a 1-element int32 tensor on the mask's device")
+        if plan is not None:
+            S = ctypes.c_int64(0)
+            nat.check(nat.lib().litho_abbe_accumulate_planned(nat.ptr(m), nat.ptr(p), planes, nat.ptr(sh),
+                                                              nat.ptr(count) if count is not None else None, sh.shape[0],
+                                                              pn, int(N), nat.ptr(out), nat.ptr(ws), ws.numel(),
+                                                              nat.stream_ptr(dev), ctypes.byref(plan.record), ctypes.byref(S)),
+                      "litho_abbe_accumulate_planned")
+            return out, S.value
         if count is not None:
-            if count.dtype != torch.int32 or count.numel() != 1 or count.device != m.device:
-                raise ShapeError("count must be a 1-element int32 tensor on the mask's device")
             S = ctypes.c_int64(0)
             nat.check(nat.lib().litho_abbe_accumulate_counted(nat.ptr(m), nat.ptr(p), planes, nat.ptr(sh), nat.ptr(count),
                                                               sh.shape[0], pn, int(N), nat.ptr(out), nat.ptr(ws),
@@ -144,7 +175,8 @@ def _all_reduce_sum(image, group):
 
 
 def abbeImage(mask, maskFT: torch.Tensor, pupilF: torch.Tensor, lightsource: torch.Tensor, pixelSize: int,
-              deltaK: float, wavelength, fft: bool, device: torch.device, group=None, normalize: bool = False):
+              deltaK: float, wavelength, fft: bool, device: torch.device, group=None, normalize: bool = False,
+              plan_cache: PlanCache = None):
     """Drop-in for imageformation.py:47-77.  `pupilF` may also be a through-focus stack [planes,pn,pn] (BASELINE
     config 5; the reference's counterpart is a Python loop over Pupil(...) + abbeImage(...)), in which case the
     result is [planes,pn',pn'].
@@ -154,7 +186,10 @@ def abbeImage(mask, maskFT: torch.Tensor, pupilF: torch.Tensor, lightsource: tor
     shards, one per rank, and the partial intensities are summed with ONE all-reduce (RCCL
     over xGMI on MI355X) before the linear post-process (SURVEY 8e).
 
-    `normalize`: divide by the number of source points S (SURVEY 8f #3; the reference returns raw sums, Q7)."""
+    `normalize`: divide by the number of source points S (the reference returns raw sums, Q7).
+
+    `plan_cache`: optional PlanCache for sequences of images with the same pupil and source (single GPU): from the second
+    call on, no source compaction, no planning launches and no host wait."""
     if not fft:
         raise NotImplementedError("only the FFT formulation (fft=True) is built; the direct integral "
                                   "(imageformation.py:3-30) is outside the hot path")
@@ -171,7 +206,17 @@ def abbeImage(mask, maskFT: torch.Tensor, pupilF: torch.Tensor, lightsource: tor
     maskFT = maskFT.to(dev)
     from .distributed import resolve_group, shard_bounds
     group = resolve_group(group)
-    if group is None:
+    if group is None and plan_cache is not None:
+        planes = pupilF.shape[0] if pupilF.dim() == 3 else 1
+        r = plan_cache.record
+        if plan_cache.shifts is None or not plan_cache.valid or (r.pn, r.N, r.planes) != (pixelNumber, int(N), planes):
+            plan_cache.invalidate()
+            plan_cache.shifts, plan_cache.count = sourceShiftsAsync(lightsource.to(dev), pixelNumber)
+            image, total = abbeIntensity(maskFT, pupilF.to(dev), plan_cache.shifts, N, count=plan_cache.count, plan=plan_cache)
+            plan_cache.S, plan_cache.count = total, None           # the count is on the host now (and in the record)
+        else:
+            image, total = abbeIntensity(maskFT, pupilF.to(dev), plan_cache.shifts, N, plan=plan_cache)
+    elif group is None:
         # single GPU: the source count never visits the host on its own -- one stream wait per image
         shifts, count = sourceShiftsAsync(lightsource.to(dev), pixelNumber)          # imageformation.py:59
         image, total = abbeIntensity(maskFT, pupilF.to(dev), shifts, N, count=count)  # imageformation.py:62-67

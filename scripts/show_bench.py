@@ -19,4 +19,6 @@ for e in r.get("extra_workloads", []):
         print("  extra", e["workload"], "ERROR", e["error"])
         continue
     print(f"  extra {e['workload'][:40]:40s} {e['ms_per_step']:10.2f} ms/step  {e['value']:.3e}  {e['dominant_kernel']} "
-          f"(time {e['dominant_kernel_time_frac']:.2f}, valu {e['dominant_kernel_valu_frac']:.2f})")
+          f"(time {e['dominant_kernel_time_frac']:.2f}, valu {e['dominant_kernel_valu_frac']:.2f})"
+          + (f"  [sequence with PlanCache: {e['sequence_with_plan_cache']['ms_per_image']:.3f} ms, {e['sequence_with_plan_cache']['value']:.3e}]"
+             if "sequence_with_plan_cache" in e else ""))

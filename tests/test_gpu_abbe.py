@@ -514,6 +514,49 @@ def test_consecutive_shard_4096_vs_golden(golden, L, dev, monkeypatch, path):
         assert abs(float(img.double().sum()) / float(g[f"cfg4shard_{tag}_sum"]) - 1) < 2e-6
 
 
+def test_plan_cache_many_masks_one_optical_setting(L, dev):
+    """PlanCache: a sequence of images that share pupil and source (here: three masks) plans ONCE -- from the second
+    call on no source compaction, no planning launch and no host wait (plan word 15) -- and gives exactly the images of
+    the plain calls; invalidate() / a different size replans."""
+    from lithographysimulator_amd import _native as nat
+    from lithographysimulator_amd.synthetic import bernoulli_mask, lines_mask
+    pn = 256
+    bm = L.LightSource(0.0, 0.5, pn, NA, device=dev).generateAnnular()
+    pf = L.Pupil(pn, WL, NA, f16(DEMO_AB), dev).generatePupilFunction()
+    masks = [L.Mask(bernoulli_mask(pn), PS, dev), L.Mask(lines_mask(pn), PS, dev), L.Mask(1 - bernoulli_mask(pn), PS, dev)]
+    cache = L.PlanCache()
+    assert not cache.valid
+    for i, mk in enumerate(masks):
+        mft = mk.fraunhofer(WL, True)
+        plain = L.abbeImage(mk, mft, pf, bm, PS, mk.deltaK, WL, True, dev)
+        assert nat.last_plan()["planned_from_record"] == 0
+        cached = L.abbeImage(mk, mft, pf, bm, PS, mk.deltaK, WL, True, dev, plan_cache=cache)
+        assert nat.last_plan()["planned_from_record"] == (1 if i > 0 else 0) and cache.valid and cache.S == 3233
+        assert torch.equal(plain, cached), i
+        norm = L.abbeImage(mk, mft, pf, bm, PS, mk.deltaK, WL, True, dev, normalize=True, plan_cache=cache)
+        assert rel_max((norm * 3233).cpu(), plain.cpu()) < 1e-6
+    # the explicit-list form
+    sh = L.sourceShifts(bm, pn)
+    mft = masks[0].fraunhofer(WL, True)
+    eps, N = masks[0].calculateEpsilonN(masks[0].deltaK, PS, WL)
+    c2 = L.PlanCache()
+    a, S1 = L.abbeIntensity(mft, pf, sh, N, plan=c2)
+    b, S2 = L.abbeIntensity(mft, pf, sh, N, plan=c2)
+    assert S1 == S2 == 3233 and nat.last_plan()["planned_from_record"] == 1 and torch.equal(a, b)
+    assert torch.equal(a, L.abbeIntensity(mft, pf, sh, N))
+    c2.invalidate()
+    L.abbeIntensity(mft, pf, sh, N, plan=c2)
+    assert nat.last_plan()["planned_from_record"] == 0 and c2.valid
+    # another image size with the same cache object: replanned, not misused
+    mk5 = L.Mask(bernoulli_mask(512), PS, dev)
+    bm5 = L.LightSource(0.0, 0.5, 512, NA, device=dev).generateAnnular()
+    pf5 = L.Pupil(512, WL, NA, None, dev).generatePupilFunction()
+    m5 = mk5.fraunhofer(WL, True)
+    got = L.abbeImage(mk5, m5, pf5, bm5, PS, mk5.deltaK, WL, True, dev, plan_cache=cache)
+    assert nat.last_plan()["planned_from_record"] == 0 and cache.record.pn == 512
+    assert torch.equal(got, L.abbeImage(mk5, m5, pf5, bm5, PS, mk5.deltaK, WL, True, dev))
+
+
 def test_full_source_additivity_config2(L, dev):
     """BASELINE config 2 at its FULL source (S = 98,832): the image of all points == the sum of the images of 8
     contiguous balanced shards (exactly what 8 ranks accumulate before the all-reduce), and == the single-wait

@@ -605,7 +605,18 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
     if (bs > 65535) bs = 65535;
     // Balance: every y-pass group gets the same number of points (batch multiple of G) and the x-pass
     // chunks divide the batch evenly (chunk = divisor of the batch nearest 4).
+    const int64_t bs_cap = bs;
     if (kn.batch <= 0 && bs > G) bs -= bs % G;
+    // Few, long batches (small images: config 1 is 3233 points in batches of up to 825): even batches instead of full ones
+    // plus a short tail -- every launch pair costs 15-20 us before its first item (3233 = 4 x 768 + 161 was five launch
+    // pairs, 4 x 809 is four).  A ragged split over the G groups (809 = 64 x 12 + 41) costs less than that.
+    const int64_t S_plan = pl[8];
+    if (kn.batch <= 0 && S_plan > bs && S_plan <= 64 * bs_cap) {
+        const int64_t B = (S_plan + bs_cap - 1) / bs_cap;      // launch pairs needed at the cap
+        int64_t even = (S_plan + B - 1) / B;
+        if (even % G && even + (G - even % G) <= bs_cap) even += G - even % G;
+        if (even >= 1 && (S_plan + even - 1) / even < (S_plan + bs - 1) / bs) bs = even;
+    }
     int xchunk = kn.xchunk;                                    // source points per x-pass workgroup
     if (xchunk <= 0) {
         // ~4 source points per workgroup: the pupil rows (5 loads per plane) are amortised over the chunk, the

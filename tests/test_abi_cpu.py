@@ -43,6 +43,16 @@ def test_library_exports_every_declared_symbol(nat):
     assert sorted(nat.exported_symbols()) == declared_symbols()
 
 
+def test_plan_record_layout_matches_the_header(nat):
+    """litho_abbe_plan: 16 plan words + valid + pn + N + planes, all int32 (ctypes mirror: _native.PlanRecord)."""
+    text = open(HEADER).read()
+    assert "int32_t words[16];" in text and "int32_t valid;" in text and "int32_t pn, N, planes;" in text
+    assert ctypes.sizeof(nat.PlanRecord) == 20 * 4
+    assert [f[0] for f in nat.PlanRecord._fields_] == ["words", "valid", "pn", "N", "planes"]
+    # a NULL record is an argument error, not a crash (no GPU call is made)
+    assert nat.lib().litho_abbe_accumulate_planned(None, None, 1, None, None, 0, 256, 512, None, None, 0, None, None, None) == nat.E_ARG
+
+
 def test_target_arch_and_version(nat):
     assert nat.lib().litho_target_arch() == b"gfx950"
     assert nat.lib().litho_version() >= 100

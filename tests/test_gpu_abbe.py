@@ -557,6 +557,49 @@ def test_plan_cache_many_masks_one_optical_setting(L, dev):
     assert torch.equal(got, L.abbeImage(mk5, m5, pf5, bm5, PS, mk5.deltaK, WL, True, dev))
 
 
+@pytest.mark.parametrize("path", ["coarse", "direct"])
+def test_config2_full_source_vs_reference_golden(golden, L, dev, monkeypatch, path):
+    """BASELINE config 2 IN FULL against the reference ITSELF (golden g11: the reference's own abbeImage over all 98,832
+    source points, two hours of CPU; its raw accumulated intensity captured from the same run): raw and post-processed
+    image on the default (coarse-grid) and the direct path, and normalize=True against golden / S.  Tolerance 1e-4 of
+    the maximum (the reference's sequential fp32 sum of 1e5 images is itself that far from exact); the
+    observed figures are printed."""
+    from lithographysimulator_amd import _native as nat
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    g = golden("g11_config2_full.npz")
+    pn = 1024
+    if path == "direct":
+        monkeypatch.setenv("LITHO_ABBE_COARSE", "0")
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    bm = L.LightSource(0.4, 0.8, pn, NA, device=dev).generateAnnular()
+    sh = L.sourceShifts(bm, pn)
+    S = int(g["S"])
+    assert sh.shape[0] == S == 98832
+    pf = L.Pupil(pn, WL, NA, f16([0, 0, 0, 0, 100]), dev).generatePupilFunction()
+    raw = L.abbeIntensity(mft, pf, sh, N)
+    assert nat.last_plan()["coarse_grid"] == (1 if path == "coarse" else 0)
+    final = L.postProcess(raw, eps).cpu()
+    raw = raw.cpu()
+    for tag, img in (("raw", raw), ("final", final)):
+        mx = float(g[f"cfg2full_{tag}_max"])
+        e_crop = float((crop_center(img).double() - torch.from_numpy(g[f"cfg2full_{tag}_crop"]).double()).abs().max() / mx)
+        e_grid = float(np.abs(img[::8, ::8].numpy().astype(np.float64) - g[f"cfg2full_{tag}_stride8"]).max() / mx)
+        e_rows = float(np.abs(img.double().sum(1).numpy() - g[f"cfg2full_{tag}_rowsum"]).max() / g[f"cfg2full_{tag}_rowsum"].max())
+        e_cols = float(np.abs(img.double().sum(0).numpy() - g[f"cfg2full_{tag}_colsum"]).max() / g[f"cfg2full_{tag}_colsum"].max())
+        e_sum = abs(float(img.double().sum()) / float(g[f"cfg2full_{tag}_sum"]) - 1)
+        e_max = abs(float(img.max()) / mx - 1)
+        print(f"config 2 full source vs the reference, {path} path, {tag}: crop {e_crop:.2e}, stride-8 grid {e_grid:.2e}, "
+              f"row sums {e_rows:.2e}, column sums {e_cols:.2e}, total {e_sum:.2e}, max {e_max:.2e}")
+        assert max(e_crop, e_grid, e_max) < 1e-4 and max(e_rows, e_cols, e_sum) < 2e-5
+    if path == "coarse":
+        norm = L.abbeImage(mask, mft, pf, bm, PS, mask.deltaK, WL, True, dev, normalize=True).cpu()
+        e_n = float(np.abs(norm[::8, ::8].numpy().astype(np.float64) * S - g["cfg2full_final_stride8"]).max() / float(g["cfg2full_final_max"]))
+        print(f"normalize=True vs golden / S: {e_n:.2e}")
+        assert e_n < 1e-4
+
+
 def test_full_source_additivity_config2(L, dev):
     """BASELINE config 2 at its FULL source (S = 98,832): the image of all points == the sum of the images of 8
     contiguous balanced shards (exactly what 8 ranks accumulate before the all-reduce), and == the single-wait

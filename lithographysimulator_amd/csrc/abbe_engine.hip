@@ -374,7 +374,7 @@ static int env_int(const char* name, int dflt)
 
 // Tuning / test knobs.  Read ONCE per C-ABI call (the parity tests flip them between calls), never per launch.
 struct Knobs {
-    int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk, xsplit, rect, xrect, coarse, gcombine;
+    int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk, xsplit, rect, xrect, coarse, gcombine, rowpairs;
     static Knobs read()
     {
         Knobs k;
@@ -393,6 +393,7 @@ struct Knobs {
         k.xrect = env_int("LITHO_ABBE_XRECT", 1);
         k.coarse = env_int("LITHO_ABBE_COARSE", 1);
         k.gcombine = env_int("LITHO_ABBE_GCOMBINE", 1);
+        k.rowpairs = env_int("LITHO_ABBE_ROWPAIRS", 0);
         return k;
     }
 };
@@ -465,7 +466,7 @@ static void make_geom(PassGeom& g, int pn, int N, int r0, int c0, int h, int wdt
     g.pn = pn; g.c = pn / 2; g.N = N; g.nt = (pn + 3) / 4;
     g.kx0 = c0 - g.c; g.kx1 = c0 + wdt - g.c;
     g.ky0 = r0 - g.c; g.ky1 = r0 + h - g.c;
-    g.rows = h; g.general = general; g.rect_off = 0; g.gcombine = 0;
+    g.rows = h; g.general = general; g.rect_off = 0; g.gcombine = 0; g.row_pairs = 0;
     g.xmask = slot_mask(N, g.kx0, g.kx1);
     g.ymask = slot_mask(N, g.ky0, g.ky1);
     set_tile(g, h, tile_cols);
@@ -536,13 +537,18 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
     // (scripts/ubench/write_bw.hip) 2.2 TB/s for 32-byte granules (4-column tiles), 3.4 TB/s for 64-byte granules
     // (8 columns), 5.2 TB/s for whole 128-byte lines.  The wave kernels read 8-column tiles at no extra cost, the
     // radix-16 y-pass does not (measured in round 1), so: 8 columns on the wave path, 4 elsewhere.
-    if (kn.tile <= 0 && w64_shape && !kn.w64x) set_tile(g, h, 8);
+    // N = pn = 4096 (config 4's coarse grid): a T item is 67 MB, T streams through HBM, and there whole-line stores are
+    // worth 7.5 us of the x-pass's 21.6 per item -- 16-column tiles, read by k_ypass_coop (24.4 us per item against
+    // k_ypass_wave's 21.2 on 8-column tiles: 38.7 us per source point against 43.1).
+    const bool coop16 = pn == N && N == 4096 && variant == 0;
+    if (kn.tile <= 0 && w64_shape && !kn.w64x) set_tile(g, h, coop16 ? 16 : 8);
     const int tc = 1 << g.tcl;
     // k_ypass_rect: 4096 / N adjacent columns per wave (they must fit one T tile)
     const bool rect = (variant == 0 ? N <= 2048 : rect_ok && N <= 2048) && ((4096 / N) <= tc || (N == 256 && tc == 8));
     g.rect_off = rect ? 0 : 1;
     g.gcombine = kn.gcombine ? 1 : 0;
-    const bool wave_y = w64_shape && (g.tcl == 2 || g.tcl == 3) && ((N != 512 && N != 256) || rect) &&
+    g.row_pairs = (kn.rowpairs && g.tcl == 3) ? 1 : 0;
+    const bool wave_y = w64_shape && (g.tcl == 2 || g.tcl == 3 || (g.tcl == 4 && N == 4096 && variant == 0)) && ((N != 512 && N != 256) || rect) &&
                         (variant == 1 || rect || N == 4096);
 
     // y-pass groups: the grid is (column blocks) x (planes in flight) x G workgroups; pick the smallest group
@@ -731,7 +737,7 @@ static int reconstruct_plane(const SizeOps* ops, const SizeOps* ops_c, const Wor
     PassGeom gf;
     gf.pn = pn; gf.c = pn / 2; gf.N = pn; gf.nt = (pn + 3) / 4;
     gf.kx0 = -pn / 2; gf.kx1 = pn / 2; gf.ky0 = gf.kx0; gf.ky1 = gf.kx1;
-    gf.rows = pn; gf.general = 0; gf.rect_off = 0; gf.gcombine = 0;
+    gf.rows = pn; gf.general = 0; gf.rect_off = 0; gf.gcombine = 0; gf.row_pairs = 0;
     gf.xmask = slot_mask(pn, gf.kx0, gf.kx1); gf.ymask = gf.xmask;
     set_tile(gf, gf.rows);
     RealImageLoader ldr{ic, pn, 0, nullptr};
@@ -930,7 +936,7 @@ static int mask_spectrum(const int16_t* geo, int pn, double eps, int N, float2* 
     g.pn = pn; g.c = pn / 2; g.N = N; g.nt = (int)nt;
     g.kx0 = j0 - N / 2; g.kx1 = j1 - N / 2;
     g.ky0 = g.kx0; g.ky1 = g.kx1;
-    g.rows = j1 - j0; g.general = 0; g.rect_off = 0; g.gcombine = 0;
+    g.rows = j1 - j0; g.general = 0; g.rect_off = 0; g.gcombine = 0; g.row_pairs = 0;
     g.xmask = slot_mask(N, g.kx0, g.kx1);
     g.ymask = slot_mask(N, g.ky0, g.ky1);
     set_tile(g, g.rows);

@@ -30,6 +30,7 @@ struct PassGeom {
     int rect_off;           // 1: N = 2048 y-pass by the S = 32 wave kernel instead of k_ypass_rect (test knob)
     int gcombine;           // 1: k_ypass_rect puts the two groups of a column block into ONE workgroup and combines their
                             //    accumulators through LDS before the slab flush (half the flush traffic)
+    int row_pairs;          // 1: an x-pass workgroup takes two adjacent rows (N = pn = 4096: T streams through HBM, see k_xpass_abbe)
     unsigned xmask, ymask;  // bit e set: slot e can be non-zero for SOME thread (x / y input)
     long long t_point;      // float2 elements of T per source point = ceil(pn/tc)*rows*tc
 };
@@ -112,8 +113,13 @@ __device__ __forceinline__ void diag_keep(float2 v, unsigned o) { asm volatile("
 // T[s][tile][row][4].  One workgroup = one row of the box for a CHUNK of source points: the
 // pupil row and the twiddles stay in registers, only the mask-spectrum window moves.
 // ----------------------------------------------------------------------------------
-template <int LOG2N, int RL, bool PRUNED, int NP>
-__global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void k_xpass_abbe(
+// RP = 2 (row pairs): the workgroup takes rows 2a and 2a + 1, one after the other for every source point, so that both
+// 64-byte halves of a 128-byte line of T (8-column tiles: two rows per line) leave ONE CU within a microsecond and the
+// L2 writes the line back whole.  With one row per workgroup the halves come from two workgroups that drift apart by
+// more than the L2 keeps a dirty line once T streams through HBM (4096^2: 67 MB per item), and half-line write-backs
+// are what bounds the pass there.  Costs a second pupil row in registers: two workgroups per CU instead of three.
+template <int LOG2N, int RL, bool PRUNED, int NP, int RP = 1>
+__global__ __launch_bounds__(Launch<LOG2N>::THREADS, (RP == 2 ? Launch<LOG2N>::WAVES / Launch<LOG2N>::WG_PER_CU * 2 : Launch<LOG2N>::WAVES)) void k_xpass_abbe(
     const float2* __restrict__ P, const float2* __restrict__ M, const int* __restrict__ shifts,
     float2* __restrict__ Tbuf, const float2* __restrict__ twtab, PassGeom g, int nb, int chunk)
 {
@@ -137,20 +143,22 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
     // identity mapping the four quarters of every line are written from four different L2s and each
     // one evicts a partial line (measured: 3.7 of 8.5 us/point).  Blocks b, b+8, b+16, b+24 run on the
     // same XCD back to back, so they get rows 4j..4j+3 and the line is completed inside one L2.
+    static_assert(RP == 1 || (RP == 2 && NP == 1 && LC::L == 1), "row pairs: one plane, one line per workgroup");
     int a;
     if constexpr (LC::L == 1) {
         const int b = blockIdx.x, xcd = b & 7, i = b >> 3;
-        a = (i >> 2) * 32 + xcd * 4 + (i & 3);
+        a = ((i >> 2) * 32 + xcd * 4 + (i & 3)) * RP;
     } else {
         a = blockIdx.x * LC::L + lg;
     }
     const bool active = a < g.rows;
+    const bool active1 = a + 1 < g.rows;                      // RP = 2: the second row of the pair exists
     const int r = g.ky0 + g.c + a;                            // row of P inside its support box
     const size_t plane_bytes = (size_t)g.pn * g.pn * sizeof(float2);
     const __amdgpu_buffer_rsrc_t rM = make_rsrc(M, plane_bytes);
 
     unsigned koff[16];           // (c + k) of slot e, or BUF_OOB when outside the window
-    float2 pv[NP][16];
+    float2 pv[NP * RP][16];      // RP = 2: pv[1] is the pupil row r + 1
     static_for<0, 16>([&](auto e_) {
         constexpr int e = decltype(e_)::value;
         if constexpr ((IN >> e) & 1u) {
@@ -159,13 +167,13 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
             koff[e] = ok ? (unsigned)(g.c + k) : BUF_OOB;
         }
     });
-    static_for<0, NP>([&](auto p_) {
+    static_for<0, NP * RP>([&](auto p_) {
         constexpr int p = decltype(p_)::value;
-        const __amdgpu_buffer_rsrc_t rP = make_rsrc(P + (size_t)p * g.pn * g.pn, plane_bytes);
+        const __amdgpu_buffer_rsrc_t rP = make_rsrc(P + (size_t)(RP == 1 ? p : 0) * g.pn * g.pn, plane_bytes);
         static_for<0, 16>([&](auto e_) {
             constexpr int e = decltype(e_)::value;
             if constexpr ((IN >> e) & 1u)
-                pv[p][e] = buf_load_c64(rP, koff[e] != BUF_OOB ? ((unsigned)r * g.pn + koff[e]) * 8u : BUF_OOB);
+                pv[p][e] = buf_load_c64(rP, koff[e] != BUF_OOB ? ((unsigned)(r + (RP == 1 ? 0 : p)) * g.pn + koff[e]) * 8u : BUF_OOB);
         });
     });
     unsigned toff[16];           // byte offset of output bin m inside one T item
@@ -181,9 +189,9 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
 
     const int s_begin = blockIdx.y * chunk;
     const int s_end = min(nb, s_begin + chunk);
-    auto load_window = [&](int s, float2 (&mv)[16]) {
+    auto load_window = [&](int s, int rr, float2 (&mv)[16]) {
         const int dy = shifts[2 * s], dx = shifts[2 * s + 1];
-        const unsigned mrow = (unsigned)(r + dy) * g.pn + dx;          // same window of M moved by the shift
+        const unsigned mrow = (unsigned)(r + rr + dy) * g.pn + dx;     // same window of M moved by the shift
         static_for<0, 16>([&](auto e_) {
             constexpr int e = decltype(e_)::value;
             if constexpr ((IN >> e) & 1u)
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
 
     int flip = 0;
     float2 mnext[16];
-    if (s_begin < s_end) load_window(s_begin, mnext);
+    if (s_begin < s_end) load_window(s_begin, 0, mnext);
     // Consume the first window HERE, so that the compiler waits for it in the preheader.  Otherwise the loop header
     // inherits "loads may be pending" from the entry edge and opens every iteration with s_waitcnt vmcnt(0) -- which,
     // with vmcnt shared between loads and stores on gfx950, also waits for the previous iteration's eight T stores
@@ -206,39 +214,60 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, Launch<LOG2N>::WAVES) void 
         constexpr int e = decltype(e_)::value;
         if constexpr ((IN >> e) & 1u) touch_vgpr(mnext[e]);
     });
+    // RP = 2: row a + 1 sits one tile row further (the last pair of an odd box has no second row: out of range)
+    const unsigned row1 = active1 ? (8u << g.tcl) : 0x80000000u;
+    float2 held[RP == 2 ? 16 : 1];
     for (int s = s_begin; s < s_end; ++s) {
-        float2 mv[16];
-        static_for<0, 16>([&](auto e_) {
-            constexpr int e = decltype(e_)::value;
-            if constexpr ((IN >> e) & 1u) mv[e] = mnext[e];
-        });
-#ifndef LITHO_XPASS_NO_PREFETCH
-        // the next point's window is in flight while this point's NP transforms run (the LDS-only
-        // barriers of the FFT do not drain vmcnt); the last iteration re-reads its own window
-        load_window(s + 1 < s_end ? s + 1 : s, mnext);
-#else
-        if (s + 1 < s_end) load_window(s + 1, mnext);
-#endif
-        static_for<0, NP>([&](auto p_) {
-            constexpr int p = decltype(p_)::value;
-            float2 x[16];
+        static_for<0, RP>([&](auto rr_) {
+            constexpr int rr = decltype(rr_)::value;
+            float2 mv[16];
             static_for<0, 16>([&](auto e_) {
                 constexpr int e = decltype(e_)::value;
-                if constexpr ((IN >> e) & 1u) x[e] = cmul(pv[p][e], mv[e]);
-                else x[e] = make_float2(0.f, 0.f);
+                if constexpr ((IN >> e) & 1u) mv[e] = mnext[e];
             });
-            F::template run<LC::NBUF>(x, tw, lds, lt, flip);
-            const __amdgpu_buffer_rsrc_t rT =
-                make_rsrc(Tbuf + ((size_t)p * nb + s) * g.t_point, (size_t)g.t_point * sizeof(float2));
-            static_for<0, 16>([&](auto m_) {
-                constexpr int m = decltype(m_)::value;
-#ifdef LITHO_DIAG_XNOSTORE
-                if constexpr ((OUT >> m) & 1u) diag_keep(x[m], toff[m]);
-#elif defined(LITHO_DIAG_XSTORE_L2)
-                if constexpr ((OUT >> m) & 1u) buf_store_c64(rT, toff[m] == BUF_OOB ? BUF_OOB : (toff[m] & 0xFFFFFu), x[m]);
+#ifndef LITHO_XPASS_NO_PREFETCH
+            // the next window is in flight while this one's NP transforms run (the LDS-only
+            // barriers of the FFT do not drain vmcnt); the last iteration re-reads its own window
+            if constexpr (rr + 1 < RP) load_window(s, rr + 1, mnext);
+            else load_window(s + 1 < s_end ? s + 1 : s, 0, mnext);
 #else
-                if constexpr ((OUT >> m) & 1u) buf_store_c64(rT, toff[m], x[m]);
+            if constexpr (rr + 1 < RP) load_window(s, rr + 1, mnext);
+            else if (s + 1 < s_end) load_window(s + 1, 0, mnext);
 #endif
+            static_for<0, NP>([&](auto p_) {
+                constexpr int p = decltype(p_)::value;
+                float2 x[16];
+                static_for<0, 16>([&](auto e_) {
+                    constexpr int e = decltype(e_)::value;
+                    if constexpr ((IN >> e) & 1u) x[e] = cmul(pv[RP == 1 ? p : rr][e], mv[e]);
+                    else x[e] = make_float2(0.f, 0.f);
+                });
+                F::template run<LC::NBUF>(x, tw, lds, lt, flip);
+                const __amdgpu_buffer_rsrc_t rT =
+                    make_rsrc(Tbuf + ((size_t)p * nb + s) * g.t_point, (size_t)g.t_point * sizeof(float2));
+                if constexpr (RP == 2 && rr == 0) {
+                    // keep row 2a's line: it is stored together with row 2a + 1's, half line next to half line
+                    static_for<0, 16>([&](auto m_) { held[decltype(m_)::value] = x[decltype(m_)::value]; });
+                } else {
+                    static_for<0, 16>([&](auto m_) {
+                        constexpr int m = decltype(m_)::value;
+#ifdef LITHO_DIAG_XNOSTORE
+                        if constexpr ((OUT >> m) & 1u) diag_keep(x[m], toff[m]);
+#elif defined(LITHO_DIAG_XSTORE_L2)
+                        if constexpr ((OUT >> m) & 1u) buf_store_c64(rT, toff[m] == BUF_OOB ? BUF_OOB : (toff[m] & 0xFFFFFu), x[m]);
+#else
+                        if constexpr ((OUT >> m) & 1u) {
+                            if constexpr (RP == 2) {
+                                buf_store_c64(rT, toff[m], held[m]);
+                                // (BUF_OOB + row_bytes stays out of range; toff1 is out of range when row 2a + 1 does not exist)
+                                buf_store_c64(rT, toff[m] + row1, x[m]);
+                            } else {
+                                buf_store_c64(rT, toff[m], x[m]);
+                            }
+                        }
+#endif
+                    });
+                }
             });
         });
     }
@@ -746,24 +775,29 @@ template <int LOG2N>
 struct SizeImpl {
     using LC = Launch<LOG2N>;
 
-    template <int RL, bool PRUNED, int NP>
+    template <int RL, bool PRUNED, int NP, int RP = 1>
     static hipError_t xa(const float2* P, const float2* M, const int* shifts, float2* T, const float2* tw,
                          const PassGeom& g, int nb, int chunk, hipStream_t st)
     {
         static LdsOnce once;
-        auto kern = k_xpass_abbe<LOG2N, RL, PRUNED, NP>;
+        auto kern = k_xpass_abbe<LOG2N, RL, PRUNED, NP, RP>;
         hipError_t e = set_lds(once, kern, LC::LDS_BYTES);
         if (e != hipSuccess) return e;
         // L == 1: grid.x padded to a multiple of 32 for the XCD-aware row mapping in the kernel
-        dim3 grid(LC::L == 1 ? (g.rows + 31) / 32 * 32 : (g.rows + LC::L - 1) / LC::L, (nb + chunk - 1) / chunk);
+        const int wrows = (g.rows + RP - 1) / RP;              // rows (RP = 2: row pairs) to hand out
+        dim3 grid(LC::L == 1 ? (wrows + 31) / 32 * 32 : (wrows + LC::L - 1) / LC::L, (nb + chunk - 1) / chunk);
         hipLaunchKernelGGL(kern, grid, dim3(LC::THREADS), LC::LDS_BYTES, st, P, M, shifts, T, tw, g, nb, chunk);
-        note_kernel(0, PRUNED ? "k_xpass_abbe<%d, %d, true, %d>" : "k_xpass_abbe<%d, %d, false, %d>", LOG2N, RL, NP);
+        if (RP == 2) note_kernel(0, "k_xpass_abbe<%d, %d, true, %d, 2>", LOG2N, RL, NP);
+        else note_kernel(0, PRUNED ? "k_xpass_abbe<%d, %d, true, %d>" : "k_xpass_abbe<%d, %d, false, %d>", LOG2N, RL, NP);
         return hipGetLastError();
     }
     template <int RL>
     static hipError_t xa_np(int np, const float2* P, const float2* M, const int* shifts, float2* T, const float2* tw,
                             const PassGeom& g, int nb, int chunk, hipStream_t st)
     {
+        if constexpr (LOG2N == 12 && RL == 0) {
+            if (np == 1 && g.row_pairs) return xa<RL, true, 1, 2>(P, M, shifts, T, tw, g, nb, chunk, st);
+        }
         if (np == 1) return xa<RL, true, 1>(P, M, shifts, T, tw, g, nb, chunk, st);
         if constexpr (RL >= 1) {       // RL = 0 (N = pn) has 9 live input slots: 2 or 4 pupil rows would spill
             if (np == 2) return xa<RL, true, 2>(P, M, shifts, T, tw, g, nb, chunk, st);

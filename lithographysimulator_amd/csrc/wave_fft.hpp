@@ -149,20 +149,36 @@ struct WaveSq {
         }
     }
     // run() with the lane twiddles read from such a table (the caller synchronises the workgroup after filling it)
+    template <bool TABLE_FIRST = false>
     __device__ static __forceinline__ void run_lds_tw(float2 (&x)[S], const float2* tab, float* lds, int lane)
     {
+        if constexpr (TABLE_FIRST) {                   // (a caller whose inputs are still in flight from memory: the reads overlap the wait)
+            LaneTwiddles tw;
+            asm volatile("" ::: "memory");
+            static_for<1, NTW>([&](auto i_) { constexpr int i = decltype(i_)::value; if constexpr (i != 8) tw.row[i] = tab[i * 64 + lane]; });
+            run(x, tw, lds, lane);
+            return;
+        }
+        // Pass A first, the table reads after it: 30 twiddle registers on top of the 128 of x and the caller's 64
+        // accumulators during pass A are what made the callers spill (k_ypass_coop: 18 accumulators per line, to HBM).
+        dft_dif(x);                                    // slot brev(m) = y[m]
         LaneTwiddles tw;
-        asm volatile("" ::: "memory");                 // the table reads stay inside the caller's loop
+        asm volatile("" ::: "memory");                 // the table reads stay here: inside the caller's loop, behind pass A
         static_for<1, NTW>([&](auto i_) { constexpr int i = decltype(i_)::value; if constexpr (i != 8) tw.row[i] = tab[i * 64 + lane]; });
-        run(x, tw, lds, lane);
+        run_tail(x, tw, lds, lane);
     }
 
     // x: slot j = sample l + S j (natural).  On return slot brev(k2) = bin l + S k2.
     // lds: this wave's LDS_FLOATS floats; lane = 0..63.
     __device__ static __forceinline__ void run(float2 (&x)[S], const LaneTwiddles& tw, float* lds, int lane)
     {
-        const int l = lane & (S - 1), line = lane >> LS;
         dft_dif(x);                                    // slot brev(m) = y[m]
+        run_tail(x, tw, lds, lane);
+    }
+    // everything after pass A
+    __device__ static __forceinline__ void run_tail(float2 (&x)[S], const LaneTwiddles& tw, float* lds, int lane)
+    {
+        const int l = lane & (S - 1), line = lane >> LS;
         static_for<0, S>([&](auto m_) {
             constexpr int m = decltype(m_)::value;
             constexpr int a = m >> 3, b = m & 7, sl = brev(m);

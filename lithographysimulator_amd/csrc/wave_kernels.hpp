@@ -181,7 +181,7 @@ __global__ __launch_bounds__(WaveShape<LOG2N>::THREADS, WaveShape<LOG2N>::MINWAV
                 x[j] = make_float2(0.f, 0.f);
             }
         });
-        if constexpr (FULL) W::run_lds_tw(x, twlds, lds, lane);
+        if constexpr (FULL) W::template run_lds_tw<true>(x, twlds, lds, lane);
         else W::run(x, tw, lds, lane);
         // kept bins of the sub-transform: v in [-S*S/4, S*S/4)  ->  k2 in [0, S/4) and [3S/4, S)
         static_for<0, NACC>([&](auto i_) {
@@ -200,6 +200,128 @@ __global__ __launch_bounds__(WaveShape<LOG2N>::THREADS, WaveShape<LOG2N>::MINWAV
         const int n = l + S * k2;
         const int v = n < S * S / 2 ? n : n - S * S;        // bin of the sub-transform
         srow[D * v + p + g.c] += acc[i];                    // bin u = D v + p of the full line
+    });
+}
+
+// ----------------------------------------------------------------------------------
+// y-pass for the 4096-point coarse-grid transform (N = pn = 4096: BASELINE config 4) over 16-COLUMN T tiles.  At 4096^2 a
+// T item is 67 MB: T streams through HBM, where the x-pass's stores are bound by their granule -- 64-byte granules
+// (8-column tiles) 21.6 us per item, whole 128-byte lines (16-column tiles) 14.2 -- but a wave that owns one column uses
+// 8 bytes of every 128-byte row (k_ypass_wave over 16-column tiles: 21.2 -> 28.8 us per item).  Here the NW = 4 (or 8) waves of a
+// workgroup own NW adjacent columns = 8 NW bytes of every tile row, and load them cooperatively: wave w fetches that part of
+// the rows of the live slots w, w + NW, ... with NW/2 16-byte loads per lane (64 consecutive rows per instruction) and deals
+// the NW columns out to the NW waves' staging areas --
+// their transpose matrices, idle at that point.  After a barrier every wave reads its 33 live samples back with
+// compile-time slot indices and runs the same transform as k_ypass_wave<12, ., true>.  Two workgroup barriers per line
+// (like the pair-loading kernel).  NW = 4: 76 KB of LDS, two workgroups per CU that hide each other's loads; NW = 8 (143 KB,
+// one workgroup per CU, every sector requested once) leaves the load latency exposed: 44 us per item.
+// ----------------------------------------------------------------------------------
+template <int NW>
+struct CoopShape {
+    static_assert(NW == 4, "four waves share four columns (32 bytes) of a tile row");
+    static constexpr int S = 64, N = 4096, JLIVE = 16, NLIVE = 2 * JLIVE + 1;       // live slots: j <= 16 and j >= 48
+    static constexpr int WAVE_FLOATS = NLIVE * 64 * 2 + 16;                         // staging (33 x 64 float2) >= the 64 x 65 matrix; 64-byte skew between areas
+    static_assert(WAVE_FLOATS >= WaveSq<6>::LDS_FLOATS, "the staging area holds the transpose matrix");
+    static constexpr size_t LDS_BYTES = NW * (size_t)WAVE_FLOATS * sizeof(float) + (size_t)WaveSq<6>::TW_LDS_FLOAT2 * sizeof(float2);
+    static constexpr int PARTS = 16 / NW;                                           // workgroups per 16-column tile
+    static inline int grid_x(int pn) { return PARTS * (((pn + 15) / 16 + 7) / 8 * 8); }
+};
+
+template <int LOG2N, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void k_ypass_coop(
+    const float2* __restrict__ Tbuf, float* __restrict__ slab, const float2* __restrict__ twtab,
+    PassGeom g, int nb, int G, int gstride)
+{
+    static_assert(LOG2N == 12, "cooperative-loading y-pass over 16-column tiles: N = 4096");
+    using W = WaveSq<6>;
+    using CS = CoopShape<NW>;
+    constexpr int S = CS::S, N = CS::N, JLIVE = CS::JLIVE, NLIVE = CS::NLIVE, TC = 16, RB = 8 * TC;
+    constexpr int PART_BYTES = 8 * NW;                         // bytes of a tile row this workgroup owns (NW columns)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & (NW - 1);      // column inside the workgroup's part
+    float* lds = smem + wv * CS::WAVE_FLOATS;
+    float2* twlds = reinterpret_cast<float2*>(smem + NW * CS::WAVE_FLOATS);
+    W::fill_lane_twiddle_table(twlds, twtab, 1, threadIdx.x, 64 * NW);
+    __syncthreads();
+
+    // blocks b, b + 8, ... (same XCD, back to back) take the PARTS parts of one 16-column tile
+    const int b = blockIdx.x;
+    const int tile = (b / (8 * CS::PARTS)) * 8 + (b & 7), part = (b >> 3) % CS::PARTS;
+    const int qx = tile * TC + part * NW + wv;
+    const int plane = blockIdx.y / G, grp = blockIdx.y - plane * G;
+    Tbuf += (size_t)plane * nb * g.t_point;
+    slab += (size_t)plane * gstride * g.nt * 4 * g.pn;
+    const bool active = tile * TC < g.pn;
+    float acc[S];
+    static_for<0, S>([&](auto i) { acc[i] = 0.f; });
+
+    const unsigned tile_bytes = active ? (unsigned)g.rows * RB : 0u;
+    // two lanes per row: lane 2r + e takes 16 bytes = columns 2e, 2e + 1 of the workgroup's 32 bytes of row r (32 rows per load)
+    // (the lane's offsets are re-derived inside the loop, from one opaque register: hoisted, they are spilled and every
+    // line then opens with scratch reloads in front of its loads)
+    const int i0 = wv >> 1, h = wv & 1;                        // wave-uniform: this wave's slots are i0, i0 + 2, ..., rows 32 h ...
+    const unsigned sb = (unsigned)(-g.ky0 * RB + part * PART_BYTES + i0 * RB * S + h * 32 * RB);
+    const unsigned last_oob = i0 ? 0x80000000u : 0u;           // slot 33 does not exist: out of range, the load returns zeros
+    auto live_index = [](int j) constexpr { return j <= JLIVE ? j : j - (S - NLIVE); };
+
+    for (int s = grp; s < nb; s += G) {
+        __syncthreads();                                       // every wave is done with the previous line's matrices
+        const __amdgpu_buffer_rsrc_t rT =
+            make_rsrc(Tbuf + (size_t)s * g.t_point + (size_t)(active ? tile : 0) * g.rows * TC, tile_bytes);
+        // Units (slot, half of its 64 rows) wv, wv + 4, ...: the half is h = wv & 1, the slots i0 = wv >> 1, i0 + 2, ...
+        // The row offset is re-derived from one register per line: hoisted out of the loop, the 17 load offsets of a
+        // wave spill, and every load then waits for a scratch reload (vmcnt(0)) before it is issued.
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int lrow = ln >> 1, le = ln & 1;
+        const unsigned vbx = (unsigned)lrow * RB + (unsigned)le * 16u + sb;
+        constexpr int NM = (NLIVE + 1) / 2;                    // 17 slots for i0 = 0, 16 for i0 = 1
+        u32x4v v[NM];
+        static_for<0, NM>([&](auto m_) {
+            constexpr int m = decltype(m_)::value;             // slot i = i0 + 2 m: live index, j = i (i <= 16) or i + 31
+            constexpr unsigned lo = (unsigned)(RB * S * 2 * m), hi = (unsigned)(RB * S * (2 * m + S - NLIVE) - RB * N);
+            if constexpr (2 * m + 1 <= JLIVE) v[m] = __builtin_amdgcn_raw_buffer_load_b128(rT, vbx + lo, 0, 0);
+            else if constexpr (2 * m + 1 >= NLIVE) v[m] = __builtin_amdgcn_raw_buffer_load_b128(rT, vbx + (hi + last_oob), 0, 0);
+            else if constexpr (2 * m > JLIVE) v[m] = __builtin_amdgcn_raw_buffer_load_b128(rT, vbx + hi, 0, 0);
+            else v[m] = __builtin_amdgcn_raw_buffer_load_b128(rT, vbx + (i0 ? hi : lo), 0, 0);
+        });
+        // column 2e's area, this lane's row of this wave's first slot
+        float2* const dealw = reinterpret_cast<float2*>(smem + 2 * le * CS::WAVE_FLOATS) + (lrow + i0 * 64 + 32 * h);
+        static_for<0, NM>([&](auto m_) {
+            constexpr int m = decltype(m_)::value;
+            if (2 * m + 1 < NLIVE || i0 == 0) {
+                const u32x4v t = v[m];
+                dealw[m * 128] = make_float2(__uint_as_float(t.x), __uint_as_float(t.y));
+                dealw[CS::WAVE_FLOATS / 2 + m * 128] = make_float2(__uint_as_float(t.z), __uint_as_float(t.w));
+            }
+        });
+        __syncthreads();
+        float2 x[S];
+        const float2* mine = reinterpret_cast<const float2*>(lds);
+        static_for<0, S>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            if constexpr (j <= JLIVE || j >= S - JLIVE) x[j] = mine[live_index(j) * 64 + lane];
+            else x[j] = make_float2(0.f, 0.f);
+        });
+#ifndef LITHO_COOP_NOCLOBBER
+        asm volatile("" ::: "memory");                         // the transposes below reuse `mine`: keep these reads in front of them
+#endif
+        W::run_lds_tw(x, twlds, lds, lane);
+        static_for<0, S>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            const float2 v = x[W::brev(i)];
+            acc[i] = fmaf(v.x, v.x, fmaf(v.y, v.y, acc[i]));
+        });
+    }
+    if (!active || qx >= g.pn) return;
+    float* srow = slab + ((size_t)grp * g.nt * 4 + qx) * g.pn;
+    static_for<0, S>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        const int n = lane + S * i;
+        const int v = n < S * S / 2 ? n : n - S * S;
+        srow[v + g.c] += acc[i];
     });
 }
 
@@ -597,6 +719,22 @@ hipError_t launch_ypass_wave(const float2* T, float* slab, const float2* tw, con
 {
     if (g.tcl == 2) return launch_ypass_wave_tc<LOG2N, 4>(T, slab, tw, g, nb, planes, G, gstride, st);
     if (g.tcl == 3) return launch_ypass_wave_tc<LOG2N, 8>(T, slab, tw, g, nb, planes, G, gstride, st);
+    if constexpr (LOG2N == 12) {
+        if (g.tcl == 4 && g.N == g.pn) {                       // 16-column tiles: the cooperative-loading kernel
+#ifndef LITHO_COOP_WAVES
+#define LITHO_COOP_WAVES 4
+#endif
+            constexpr int NW = LITHO_COOP_WAVES;
+            static LdsOnce once;
+            auto kern = k_ypass_coop<LOG2N, NW>;
+            hipError_t e = set_lds(once, kern, CoopShape<NW>::LDS_BYTES);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(CoopShape<NW>::grid_x(g.pn), planes * G), dim3(64 * NW), CoopShape<NW>::LDS_BYTES, st, T,
+                               slab, tw, g, nb, G, gstride);
+            note_kernel(1, "k_ypass_coop<%d, %d>", LOG2N, NW);
+            return hipGetLastError();
+        }
+    }
     return hipErrorNotSupported;
 }
 

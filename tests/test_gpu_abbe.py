@@ -880,6 +880,52 @@ def _test_8192_kernels_agree_4096(L, dev, monkeypatch):
         assert rel_max(both[k], L.abbeIntensity(mft, stack[k], sel[:4], N).cpu()) < 1e-6
 
 
+def test_coarse_grid_4096_tile_layouts_agree(L, dev, monkeypatch):
+    """Config 4's coarse grid (N' = pn = 4096).  Default: 16-column T tiles + k_ypass_coop (four waves load 32 bytes of
+    every tile row together).  Against the 8-column layout (k_ypass_wave<12, 8, true>) and against the direct path on the radix-16 y-pass:
+    the full natural box, a through-focus stack, and a SMALLER off-centre box (rows beyond it are cut by the tile
+    descriptors' range check -- also inside the slots the kernel hard-wires as live), checked against the oracle."""
+    from lithographysimulator_amd import _native as nat
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    pn = 4096
+    c = pn // 2
+    monkeypatch.setenv("LITHO_ABBE_COARSE", "2")
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    pf = L.Pupil(pn, WL, NA, f16(DEMO_AB), dev).generatePupilFunction()
+    sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateQuasar(4, -math.pi / 8), pn)
+    sel = sh[(torch.arange(7, device=dev) * sh.shape[0]) // 7].contiguous()
+    new = L.abbeIntensity(mft, pf, sel, N).cpu()
+    plan = nat.last_plan()
+    assert plan["coarse_grid"] == 1 and plan["natural_box"] == 1, plan
+    assert nat.last_kernels() == ("k_xpass_abbe<12, 0, true, 1>", "k_ypass_coop<12, 4>"), nat.last_kernels()
+    t8 = _with_env(monkeypatch, L, {"LITHO_ABBE_TILE": "8"}, lambda: L.abbeIntensity(mft, pf, sel, N).cpu())
+    assert nat.last_kernels()[1] == "k_ypass_wave<12, 8, true>", nat.last_kernels()
+    r16 = _with_env(monkeypatch, L, {"LITHO_ABBE_W64": "0"}, lambda: L.abbeIntensity(mft, pf, sel[:3], N).cpu())
+    # (without the wave kernels there is no coarse grid: this is the DIRECT path on the radix-16 y-pass)
+    assert nat.last_plan()["coarse_grid"] == 0 and nat.last_kernels()[1].startswith("k_ypass_acc<13"), nat.last_kernels()
+    assert rel_max(new, t8) < 2e-6
+    assert rel_max(L.abbeIntensity(mft, pf, sel[:3], N).cpu(), r16) < 2e-6
+    # a stack: plane p of the stacked call == the single-plane call
+    stack = L.throughFocusPupils(pn, WL, NA, f16(DEMO_AB), [-90.0, 110.0], dev)
+    both = L.abbeIntensity(mft, stack, sel[:4], N).cpu()
+    assert nat.last_kernels()[1] == "k_ypass_coop<12, 4>"
+    for k in range(2):
+        assert rel_max(both[k], L.abbeIntensity(mft, stack[k], sel[:4], N).cpu()) < 1e-6
+    # a smaller, off-centre box inside the natural one: rows k in [-700, 333], columns k in [-100, 901]
+    small = torch.zeros_like(pf)
+    small[c - 700:c + 334, c - 100:c + 902] = pf[c - 700:c + 334, c - 100:c + 902]
+    got = L.abbeIntensity(mft, small, sel[:2], N).cpu()
+    plan = nat.last_plan()
+    assert plan["coarse_grid"] == 1 and plan["natural_box"] == 1 and plan["box_rows"] <= 1034 and plan["box_cols"] <= 1002, plan
+    assert nat.last_kernels()[1] == "k_ypass_coop<12, 4>"
+    ref = O().abbe_raw(mft.cpu(), small.cpu(), sel[:2].cpu(), N)
+    e = rel_max(got, ref)
+    print(f"4096^2 coarse grid, small off-centre box {plan['box_rows']} x {plan['box_cols']}: rel-to-max {e:.2e}")
+    assert e < TOL_IMAGE_MAX and rel_l2(got, ref) < TOL_IMAGE_L2
+
+
 def test_stack_through_wave_kernel_2048(L, dev):
     """A through-focus stack (planes > 1) at 2048^2 goes plane by plane through the same kernels:
     plane p of the stacked call == the single-plane call with pupil p."""

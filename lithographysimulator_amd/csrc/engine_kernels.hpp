@@ -104,6 +104,8 @@ __device__ __forceinline__ unsigned t_offset(const PassGeom& g, unsigned a, unsi
     return ((((q >> g.tcl) * g.rows + a) << g.tcl) + (q & ((1u << g.tcl) - 1u)));
 }
 
+typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
+
 // an empty asm that "uses and redefines" a register pair: pins where the compiler must have waited for a load
 __device__ __forceinline__ void touch_vgpr(float2& v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
 __device__ __forceinline__ void diag_keep(float2 v, unsigned o) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(o)); }
@@ -113,11 +115,12 @@ __device__ __forceinline__ void diag_keep(float2 v, unsigned o) { asm volatile("
 // T[s][tile][row][4].  One workgroup = one row of the box for a CHUNK of source points: the
 // pupil row and the twiddles stay in registers, only the mask-spectrum window moves.
 // ----------------------------------------------------------------------------------
-// RP = 2 (row pairs): the workgroup takes rows 2a and 2a + 1, one after the other for every source point, so that both
-// 64-byte halves of a 128-byte line of T (8-column tiles: two rows per line) leave ONE CU within a microsecond and the
-// L2 writes the line back whole.  With one row per workgroup the halves come from two workgroups that drift apart by
-// more than the L2 keeps a dirty line once T streams through HBM (4096^2: 67 MB per item), and half-line write-backs
-// are what bounds the pass there.  Costs a second pupil row in registers: two workgroups per CU instead of three.
+// RP = 2 (row pairs, opt-in: LITHO_ABBE_ROWPAIRS): the workgroup takes rows 2a and 2a + 1, one after the other for every
+// source point, and stores them blended so that every store instruction writes whole 128-byte lines of 8-column tiles
+// (two rows per line).  Measured at 4096^2 (T streams through HBM), us per item: one row per workgroup 21.6; pairs with
+// the two rows' stores merely interleaved 19.8, half-wave by half-wave (v_permlane32_swap) 20.6, blended 19.6 -- against
+// 14.0 for one row per workgroup on 16-column tiles, which is what the planner picks there.  Costs a second pupil row and
+// a held output row in registers: two workgroups per CU instead of three.
 template <int LOG2N, int RL, bool PRUNED, int NP, int RP = 1>
 __global__ __launch_bounds__(Launch<LOG2N>::THREADS, (RP == 2 ? Launch<LOG2N>::WAVES / Launch<LOG2N>::WG_PER_CU * 2 : Launch<LOG2N>::WAVES)) void k_xpass_abbe(
     const float2* __restrict__ P, const float2* __restrict__ M, const int* __restrict__ shifts,
@@ -214,9 +217,21 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, (RP == 2 ? Launch<LOG2N>::W
         constexpr int e = decltype(e_)::value;
         if constexpr ((IN >> e) & 1u) touch_vgpr(mnext[e]);
     });
-    // RP = 2: row a + 1 sits one tile row further (the last pair of an odd box has no second row: out of range)
+    // RP = 2: row a + 1 sits one tile row further (the last pair of an odd box has no second row: out of range).
+    // The two rows are stored BLENDED: with B' = row a + 1 rotated by 8 lanes inside every 16-lane row (one DPP move),
+    // C = (lane & 8 ? B' : A) holds, in every 16 consecutive lanes, row a and row a + 1 of ONE 8-column tile -- a whole
+    // 128-byte line (8-column tiles: rows 2i, 2i + 1 of a tile are one line) -- and D = (lane & 8 ? A : B') the same
+    // for the odd tiles: every store instruction writes whole lines.  Offsets: C = toff + (hi ? row1 - tile : 0),
+    // D = toff + (hi ? 0 : row1 + tile), tile = the byte distance of neighbouring tiles.
     const unsigned row1 = active1 ? (8u << g.tcl) : 0x80000000u;
     float2 held[RP == 2 ? 16 : 1];
+    const bool hi8 = (threadIdx.x & 8) != 0;
+    unsigned offc = 0, offd = 0;
+    if constexpr (RP == 2) {
+        const unsigned tileb = (unsigned)g.rows * (8u << g.tcl);
+        offc = hi8 ? row1 - tileb : 0u;
+        offd = hi8 ? 0u : row1 + tileb;
+    }
     for (int s = s_begin; s < s_end; ++s) {
         static_for<0, RP>([&](auto rr_) {
             constexpr int rr = decltype(rr_)::value;
@@ -258,9 +273,13 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, (RP == 2 ? Launch<LOG2N>::W
 #else
                         if constexpr ((OUT >> m) & 1u) {
                             if constexpr (RP == 2) {
-                                buf_store_c64(rT, toff[m], held[m]);
-                                // (BUF_OOB + row_bytes stays out of range; toff1 is out of range when row 2a + 1 does not exist)
-                                buf_store_c64(rT, toff[m] + row1, x[m]);
+                                // (N = pn: every column exists; a padding workgroup's BUF_OOB + offd would wrap into range)
+                                if (active) {
+                                    const float bx = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x[m].x), 0x128, 0xF, 0xF, false));   // row_ror:8
+                                    const float by = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x[m].y), 0x128, 0xF, 0xF, false));
+                                    buf_store_c64(rT, toff[m] + offc, hi8 ? make_float2(bx, by) : held[m]);
+                                    buf_store_c64(rT, toff[m] + offd, hi8 ? held[m] : make_float2(bx, by));
+                                }
                             } else {
                                 buf_store_c64(rT, toff[m], x[m]);
                             }

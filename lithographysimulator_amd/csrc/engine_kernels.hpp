@@ -806,8 +806,7 @@ struct SizeImpl {
         const int wrows = (g.rows + RP - 1) / RP;              // rows (RP = 2: row pairs) to hand out
         dim3 grid(LC::L == 1 ? (wrows + 31) / 32 * 32 : (wrows + LC::L - 1) / LC::L, (nb + chunk - 1) / chunk);
         hipLaunchKernelGGL(kern, grid, dim3(LC::THREADS), LC::LDS_BYTES, st, P, M, shifts, T, tw, g, nb, chunk);
-        if (RP == 2) note_kernel(0, "k_xpass_abbe<%d, %d, true, %d, 2>", LOG2N, RL, NP);
-        else note_kernel(0, PRUNED ? "k_xpass_abbe<%d, %d, true, %d>" : "k_xpass_abbe<%d, %d, false, %d>", LOG2N, RL, NP);
+        note_kernel(0, PRUNED ? "k_xpass_abbe<%d, %d, true, %d, %d>" : "k_xpass_abbe<%d, %d, false, %d, %d>", LOG2N, RL, NP, RP);   // as rocprofv3 prints it
         return hipGetLastError();
     }
     template <int RL>

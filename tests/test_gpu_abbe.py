@@ -506,7 +506,7 @@ def test_consecutive_shard_4096_vs_golden(golden, L, dev, monkeypatch, path):
     kx, ky = nat.last_kernels()
     if path.startswith("coarse"):
         assert ky == ("k_ypass_coop<12, 4>" if path == "coarse" else "k_ypass_wave<12, 8, true>"), (kx, ky)
-        assert kx == ("k_xpass_abbe<12, 0, true, 1, 2>" if "rowpairs" in path else "k_xpass_abbe<12, 0, true, 1>"), (kx, ky)
+        assert kx == ("k_xpass_abbe<12, 0, true, 1, 2>" if "rowpairs" in path else "k_xpass_abbe<12, 0, true, 1, 1>"), (kx, ky)
     final = L.postProcess(raw, eps).cpu()
     raw = raw.cpu()
     assert tuple(final.shape) == (4094, 4094) == tuple(g["cfg4shard_final_shape"])
@@ -899,7 +899,7 @@ def test_coarse_grid_4096_tile_layouts_agree(L, dev, monkeypatch):
     new = L.abbeIntensity(mft, pf, sel, N).cpu()
     plan = nat.last_plan()
     assert plan["coarse_grid"] == 1 and plan["natural_box"] == 1, plan
-    assert nat.last_kernels() == ("k_xpass_abbe<12, 0, true, 1>", "k_ypass_coop<12, 4>"), nat.last_kernels()
+    assert nat.last_kernels() == ("k_xpass_abbe<12, 0, true, 1, 1>", "k_ypass_coop<12, 4>"), nat.last_kernels()
     t8 = _with_env(monkeypatch, L, {"LITHO_ABBE_TILE": "8"}, lambda: L.abbeIntensity(mft, pf, sel, N).cpu())
     assert nat.last_kernels()[1] == "k_ypass_wave<12, 8, true>", nat.last_kernels()
     r16 = _with_env(monkeypatch, L, {"LITHO_ABBE_W64": "0"}, lambda: L.abbeIntensity(mft, pf, sel[:3], N).cpu())

@@ -227,6 +227,11 @@ struct CoopShape {
     static inline int grid_x(int pn) { return PARTS * (((pn + 15) / 16 + 7) / 8 * 8); }
 };
 
+#ifdef LITHO_DIAG_COOP_NOLOAD
+#define COOP_LOAD(r, off) u32x4v{(off), 0x3f800000u, (off) >> 3, 0x3f000000u}
+#else
+#define COOP_LOAD(r, off) __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0)
+#endif
 template <int LOG2N, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void k_ypass_coop(
     const float2* __restrict__ Tbuf, float* __restrict__ slab, const float2* __restrict__ twtab,
@@ -282,10 +287,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ypass_coop(
         static_for<0, NM>([&](auto m_) {
             constexpr int m = decltype(m_)::value;             // slot i = i0 + 2 m: live index, j = i (i <= 16) or i + 31
             constexpr unsigned lo = (unsigned)(RB * S * 2 * m), hi = (unsigned)(RB * S * (2 * m + S - NLIVE) - RB * N);
-            if constexpr (2 * m + 1 <= JLIVE) v[m] = __builtin_amdgcn_raw_buffer_load_b128(rT, vbx + lo, 0, 0);
-            else if constexpr (2 * m + 1 >= NLIVE) v[m] = __builtin_amdgcn_raw_buffer_load_b128(rT, vbx + (hi + last_oob), 0, 0);
-            else if constexpr (2 * m > JLIVE) v[m] = __builtin_amdgcn_raw_buffer_load_b128(rT, vbx + hi, 0, 0);
-            else v[m] = __builtin_amdgcn_raw_buffer_load_b128(rT, vbx + (i0 ? hi : lo), 0, 0);
+            if constexpr (2 * m + 1 <= JLIVE) v[m] = COOP_LOAD(rT, vbx + lo);
+            else if constexpr (2 * m + 1 >= NLIVE) v[m] = COOP_LOAD(rT, vbx + (hi + last_oob));
+            else if constexpr (2 * m > JLIVE) v[m] = COOP_LOAD(rT, vbx + hi);
+            else v[m] = COOP_LOAD(rT, vbx + (i0 ? hi : lo));
         });
         // column 2e's area, this lane's row of this wave's first slot
         float2* const dealw = reinterpret_cast<float2*>(smem + 2 * le * CS::WAVE_FLOATS) + (lrow + i0 * 64 + 32 * h);

@@ -32,10 +32,13 @@ build/abbe_engine.o: $(CSRC)/abbe_engine.hip $(HDRS)
 build/optics.o: $(CSRC)/optics.hip $(CSRC)/engine_common.hpp include/litho_abbe.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -c $< -o $@
+build/layout.o: $(CSRC)/layout.hip $(CSRC)/engine_common.hpp include/litho_abbe.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -c $< -o $@
 build/common.o: $(CSRC)/common.hip $(CSRC)/engine_common.hpp include/litho_abbe.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-$(OUT): build/abbe_engine.o build/optics.o build/common.o $(INST) $(INSTW)
+$(OUT): build/abbe_engine.o build/optics.o build/layout.o build/common.o $(INST) $(INSTW)
 	@mkdir -p lithographysimulator_amd/lib
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 

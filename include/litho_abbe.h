@@ -142,6 +142,17 @@ int litho_postprocess(const float *raw, int planes, int pn, double epsilon, floa
 int litho_postprocess_resist(const float *raw, int planes, int pn, double epsilon, double gain, double threshold,
                              float *out, uint8_t *resist, void *stream);
 
+/* ---- Layout rasteriser: the device side of the GDSII import (lithographysimulator_amd/layout.py).  SURVEY.md section
+ * 8(f) row 4: the reference has NO counterpart (README.md:20-22 lists GDSII import among its unbuilt goals), it is the
+ * caller side of Mask(geometry, pixelSize) (mask.py:5-30), so there is no parity target; checked bit for bit against
+ * oracle/layout_oracle.py.  edges: fp64 [n_edges][4] = (x0, y0, x1, y1) of closed, counter-clockwise polygons, same
+ * length unit as x0 / y0 / pixel.  geometry int16 [pn][pn]: pixel (r, c) = 1 when its centre
+ * (x0 + (c + 0.5) pixel, y0 + (r + 0.5) pixel) has a non-zero winding number (half-open: a centre on a left / bottom
+ * edge is inside, on a right / top edge outside), else 0.  work: litho_rasterize_work_bytes(pn) device bytes. */
+size_t litho_rasterize_work_bytes(int pn);
+int litho_rasterize_edges(const double *edges, int64_t n_edges, int pn, double x0, double y0, double pixel, void *work,
+                          size_t work_bytes, int16_t *geometry, void *stream);
+
 /* ---- Mask spectrum pre-step: Mask._ffFraunhofer (mask.py:74-90).  geometry int16
  * [pn,pn]; spectrum complex64 [pn,pn].  Uses the same workspace as the Abbe calls. */
 int litho_mask_spectrum(const int16_t *geometry, int pn, double epsilon, int N, void *spectrum,

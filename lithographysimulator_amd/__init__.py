@@ -2,6 +2,8 @@
 quarterwave0/LithographySimulator (Mask / LightSource / Pupil / abbeImage)."""
 from .imageformation import (PlanCache, abbeImage, abbeIntensity, calculateFFTAerial, postProcess,   # noqa: F401
                              resistContour)
+from .layout import (GdsLibrary, flattenLayout, maskFromGDSII, rasterizeLayout, readGDSII,  # noqa: F401
+                     writeGDSII)
 from .lightsource import LightSource, sourceShifts, sourceShiftsAsync                                      # noqa: F401
 from .mask import Mask                                                                  # noqa: F401
 from .pupil import (OSAindexToMN, Pupil, generatePhi, generateWavefrontError,           # noqa: F401
@@ -9,4 +11,4 @@ from .pupil import (OSAindexToMN, Pupil, generatePhi, generateWavefrontError,   
 
 __all__ = ["Mask", "LightSource", "Pupil", "abbeImage", "abbeIntensity", "calculateFFTAerial", "postProcess", "resistContour", "PlanCache",
            "sourceShifts", "sourceShiftsAsync", "OSAindexToMN", "generateWavefrontError", "generatePhi", "generateZ",
-           "throughFocusPupils"]
+           "throughFocusPupils", "readGDSII", "writeGDSII", "flattenLayout", "rasterizeLayout", "maskFromGDSII", "GdsLibrary"]

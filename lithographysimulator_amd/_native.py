@@ -36,6 +36,8 @@ _SIGNATURES = {
     "litho_postprocess": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p]),
     "litho_postprocess_resist": (c_int, [c_void_p, c_int, c_int, c_double, c_double, c_double, c_void_p, c_void_p, c_void_p]),
     "litho_mask_spectrum": (c_int, [c_void_p, c_int, c_double, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "litho_rasterize_work_bytes": (c_size_t, [c_int]),
+    "litho_rasterize_edges": (c_int, [c_void_p, c_int64, c_int, c_double, c_double, c_double, c_void_p, c_size_t, c_void_p, c_void_p]),
     "litho_abbe_last_plan": (c_int, [POINTER(c_int64)]),
     "litho_abbe_last_kernels": (c_int, [c_void_p, c_void_p, c_size_t]),
     "litho_abbe_set_profiling": (c_int, [c_int]),
@@ -153,6 +155,10 @@ def last_plan():
             "planes_in_flight", "groups_per_plane", "xchunk", "fused_xpass", "coarse_grid", "wave_ypass", "natural_box",
             "planned_from_record")
     return dict(zip(keys, list(arr)))
+
+
+def rasterize_work_bytes(pn: int) -> int:
+    return int(lib().litho_rasterize_work_bytes(int(pn)))
 
 
 def last_kernels():

@@ -1,0 +1,105 @@
+// layout.hip -- polygon rasteriser behind litho_rasterize_edges: the device side of the layout import
+// (lithographysimulator_amd/layout.py; SURVEY.md section 8(f) row 4 -- the reference has no counterpart, README.md:20-22
+// lists GDSII import as an unbuilt goal, so there is no parity target; the checker is a CPU restatement in the test tree, bit for bit).
+//
+// A pixel is 1 when its centre lies inside the union of the polygons: non-zero winding number, all polygons
+// counter-clockwise (the host side orients them), half-open on edges.  Two kernels, integer arithmetic after the
+// crossing abscissa (so the result does not depend on the order the atomics land in):
+//   k_raster_edges   one thread per edge: for every pixel row whose centre ordinate yc lies in [ymin, ymax) of the edge,
+//                    the crossing x = x0 + (yc - y0) (x1 - x0) / (y1 - y0) (fp64, no contraction: Makefile) gives
+//                    k = #columns whose centre is left of it; the centres left of an upward edge gain +1, of a downward
+//                    edge -1:  delta[row][0] += dir, delta[row][k] -= dir  (int32 atomics, [pn][pn + 1]).
+//   k_raster_fill    one workgroup per row: prefix sum of delta = winding number of every centre; geometry = (w != 0).
+#include "engine_common.hpp"
+#include "../../include/litho_abbe.h"
+
+#include <cmath>
+#include <cstdint>
+
+namespace litho {
+
+__global__ __launch_bounds__(256) void k_raster_edges(const double* __restrict__ edges, int ne, int pn, double ox, double oy,
+                                                      double ps, int* __restrict__ delta)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ne) return;
+    const double x0 = edges[4 * e], y0 = edges[4 * e + 1], x1 = edges[4 * e + 2], y1 = edges[4 * e + 3];
+    if (!(y0 == y0 && y1 == y1 && x0 == x0 && x1 == x1) || y0 == y1) return;      // NaN or horizontal: no crossing
+    const int dir = y1 > y0 ? 1 : -1;
+    const double ymin = y0 < y1 ? y0 : y1, ymax = y0 < y1 ? y1 : y0;
+    // candidate rows: one spare on both sides, the exact test below decides
+    double rlo = floor((ymin - oy) / ps - 0.5) - 1.0, rhi = ceil((ymax - oy) / ps - 0.5) + 1.0;
+    if (rlo < 0.0) rlo = 0.0;
+    if (rhi > (double)(pn - 1)) rhi = (double)(pn - 1);
+    if (!(rlo <= rhi)) return;
+    const double slope_num = x1 - x0, slope_den = y1 - y0;
+    for (int r = (int)rlo; r <= (int)rhi; ++r) {
+        const double yc = oy + ((double)r + 0.5) * ps;
+        if (!(ymin <= yc && yc < ymax)) continue;
+        const double xc = x0 + ((yc - y0) * slope_num) / slope_den;
+        double t = ceil((xc - ox) / ps - 0.5);                 // columns c with ox + (c + 0.5) ps < xc
+        if (t < 0.0) t = 0.0;
+        if (t > (double)pn) t = (double)pn;
+        const int k = (int)t;
+        if (k == 0) continue;                                  // nothing lies left of the crossing
+        int* row = delta + (size_t)r * (pn + 1);
+        atomicAdd(row, dir);
+        atomicAdd(row + k, -dir);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_raster_fill(const int* __restrict__ delta, int pn, int16_t* __restrict__ geo)
+{
+    __shared__ int part[256];
+    const int r = blockIdx.x, t = threadIdx.x;
+    const int per = (pn + 255) / 256;                          // consecutive columns per thread
+    const int c0 = t * per, c1 = min(pn, c0 + per);
+    const int* row = delta + (size_t)r * (pn + 1);
+    int s = 0;
+    for (int c = c0; c < c1; ++c) s += row[c];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {                  // inclusive scan of the 256 partial sums
+        const int v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int w = t ? part[t - 1] : 0;
+    for (int c = c0; c < c1; ++c) {
+        w += row[c];
+        geo[(size_t)r * pn + c] = w != 0 ? 1 : 0;
+    }
+}
+
+}  // namespace litho
+
+extern "C" {
+
+size_t litho_rasterize_work_bytes(int pn)
+{
+    if (pn < 1) return 0;
+    return (size_t)pn * (size_t)(pn + 1) * sizeof(int);
+}
+
+int litho_rasterize_edges(const double* edges, int64_t n_edges, int pn, double x0, double y0, double pixel, void* work,
+                          size_t work_bytes, int16_t* geometry, void* stream)
+{
+    using namespace litho;
+    if (pn < 1 || pn > 32768 || n_edges < 0 || n_edges > 0x7FFFFFFF || !(pixel > 0.0) || !(x0 == x0) || !(y0 == y0) || !geometry ||
+        !work || (n_edges > 0 && !edges))
+        return LITHO_E_ARG;
+    if (work_bytes < litho_rasterize_work_bytes(pn)) return LITHO_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(work, 0, litho_rasterize_work_bytes(pn), st));
+    if (n_edges > 0) {
+        hipLaunchKernelGGL(k_raster_edges, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, st, edges, (int)n_edges, pn, x0, y0,
+                           pixel, (int*)work);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_raster_fill, dim3(pn), dim3(256), 0, st, (const int*)work, pn, geometry);
+    HIP_TRY(hipGetLastError());
+    return LITHO_OK;
+}
+
+}  // extern "C"

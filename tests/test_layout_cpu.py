@@ -1,0 +1,153 @@
+"""Layout import, host side (no GPU): the GDSII stream reader / writer, hierarchy flattening, path outlines, and the
+CPU restatement of the rasteriser against closed-form cases.  The reference has no layout import (README.md:20-22 names
+it as a goal), so these are known-answer tests, not reference goldens."""
+import numpy as np
+import pytest
+
+from lithographysimulator_amd import layout as LY
+from oracle import layout_oracle as LO
+
+
+def rect(x0, y0, x1, y1):
+    return np.array([[x0, y0], [x1, y0], [x1, y1], [x0, y1]], dtype=np.int64)
+
+
+def test_real8_known_values():
+    """The UNITS record of every nanometre-database file holds 1e-3 (user units) and 1e-9 (metres) per database unit;
+    the bytes below are what stream writers in the field put there (the last mantissa digits differ between tools)."""
+    assert LY.real8_decode(bytes.fromhex("3e4189374bc6a7ef")) == pytest.approx(1e-3, rel=1e-15)
+    for tail in ("51", "52", "53", "54"):
+        assert LY.real8_decode(bytes.fromhex("3944b82fa09b5a" + tail)) == pytest.approx(1e-9, rel=1e-15)
+    assert LY.real8_decode(bytes.fromhex("4110000000000000")) == 1.0
+    assert LY.real8_decode(bytes.fromhex("c120000000000000")) == -2.0
+    assert LY.real8_decode(bytes.fromhex("425a000000000000")) == 90.0
+    assert LY.real8_encode(1.0).hex() == "4110000000000000" and LY.real8_encode(-2.0).hex() == "c120000000000000"
+    assert LY.real8_encode(90.0).hex() == "425a000000000000" and LY.real8_encode(0.0) == bytes(8)
+    assert LY.real8_encode(1e-3).hex()[:14] == "3e4189374bc6a7" and LY.real8_encode(1e-9).hex()[:14] == "3944b82fa09b5a"
+    for v in (1e-3, 1e-9, 1.0, -2.0, 90.0, 0.5, 1234.5678, -1e-6, 6.25e-2, 16.0, 15.999999, 1e-12, 3.3e7):
+        b = LY.real8_encode(v)
+        assert LY.real8_decode(b) == pytest.approx(v, rel=1e-15)
+        assert LY.real8_encode(LY.real8_decode(b)) == b                               # a decoded real encodes back to its bytes
+    with pytest.raises(OverflowError):
+        LY.real8_encode(1e80)
+
+
+def small_library():
+    lib = LY.GdsLibrary("TESTLIB", 1e-3, 1e-9)
+    cell = LY.GdsStructure("CELL")
+    cell.elements.append(LY.GdsElement("boundary", layer=1, datatype=0, xy=np.vstack([rect(0, 0, 100, 50), [[0, 0]]])))
+    cell.elements.append(LY.GdsElement("boundary", layer=2, datatype=5, xy=np.vstack([rect(10, 10, 20, 20), [[10, 10]]])))
+    top = LY.GdsStructure("TOP")
+    top.elements.append(LY.GdsElement("sref", sname="CELL", xy=np.array([[1000, 2000]])))
+    top.elements.append(LY.GdsElement("sref", sname="CELL", xy=np.array([[0, 0]]), transform=LY.Transform(False, 1.0, 90.0)))
+    top.elements.append(LY.GdsElement("sref", sname="CELL", xy=np.array([[0, -500]]), transform=LY.Transform(True, 2.0, 0.0)))
+    top.elements.append(LY.GdsElement("aref", sname="CELL", xy=np.array([[5000, 0], [5000 + 3 * 200, 0], [5000, 2 * 300]]), cols=3, rows=2))
+    top.elements.append(LY.GdsElement("path", layer=1, datatype=0, width=20, pathtype=2, xy=np.array([[0, 1000], [300, 1000], [300, 1400]])))
+    top.elements.append(LY.GdsElement("box", layer=1, datatype=0, xy=np.vstack([rect(-400, -400, -300, -350), [[-400, -400]]])))
+    lib.structures["CELL"] = cell
+    lib.structures["TOP"] = top
+    return lib
+
+
+def test_stream_round_trip_and_record_grammar():
+    lib = small_library()
+    blob = LY.writeGDSII(lib)
+    assert blob[:4] == bytes([0, 6, 0, 2]) and blob[-4:] == bytes([0, 4, 4, 0])      # HEADER first, ENDLIB last
+    back = LY.readGDSII(blob + bytes(2048 - len(blob) % 2048))                          # with tape-block zero padding
+    assert back.name == "TESTLIB" and back.user_unit == pytest.approx(1e-3) and back.user_unit_m == pytest.approx(1e-9)
+    assert list(back.structures) == ["CELL", "TOP"] and back.top_structures() == ["TOP"]
+    for name in lib.structures:
+        a, b = lib.structures[name].elements, back.structures[name].elements
+        assert len(a) == len(b)
+        for ea, eb in zip(a, b):
+            assert (ea.kind, ea.layer, ea.datatype, ea.width, ea.pathtype, ea.sname, ea.cols, ea.rows) == \
+                   (eb.kind, eb.layer, eb.datatype, eb.width, eb.pathtype, eb.sname, eb.cols, eb.rows)
+            assert np.array_equal(np.asarray(ea.xy), eb.xy)
+            assert ea.transform.reflect == eb.transform.reflect
+            assert ea.transform.mag == pytest.approx(eb.transform.mag) and ea.transform.angle_deg == pytest.approx(eb.transform.angle_deg)
+    assert LY.writeGDSII(back) == blob                                                   # and the writer is stable
+    with pytest.raises(ValueError):
+        LY.readGDSII(b"\x00\x08\x05\x02" + bytes(4))                                     # no HEADER
+    with pytest.raises(ValueError):
+        LY.readGDSII(blob[:40] + b"\xff\xff\x10\x03")                                    # a record running off the end
+
+
+def bbox(p):
+    return tuple(np.concatenate([p.min(axis=0), p.max(axis=0)]).round(9))
+
+
+def test_flatten_transforms_and_layers():
+    lib = LY.readGDSII(LY.writeGDSII(small_library()))
+    polys = LY.flattenLayout(lib, "TOP", layers=[(1, None)])
+    boxes = sorted(bbox(p) for p in polys)
+    expect = [
+        (1000, 2000, 1100, 2050),                    # plain placement
+        (-50, 0, 0, 100),                            # rotated by 90 degrees: (x, y) -> (-y, x)
+        (0, -600, 200, -500),                        # mirrored about x, magnified 2x, placed at (0, -500)
+        (-400, -400, -300, -350),                    # BOX
+        (-10, 990, 310, 1410),                       # path, width 20, ends extended by 10
+    ] + [(5000 + 200 * i, 300 * j, 5100 + 200 * i, 50 + 300 * j) for i in range(3) for j in range(2)]
+    assert boxes == sorted(tuple(float(v) for v in b) for b in expect)
+    for p in polys:                                  # everything comes out counter-clockwise, also the mirrored copy
+        assert np.sum(p[:, 0] * np.roll(p[:, 1], -1) - np.roll(p[:, 0], -1) * p[:, 1]) > 0
+    assert len(LY.flattenLayout(lib, "TOP", layers=[(2, 5)])) == 9 and len(LY.flattenLayout(lib, "TOP", layers=[(2, 4)])) == 0
+    assert len(LY.flattenLayout(lib, "TOP")) == len(polys) + 9
+    assert len(LY.flattenLayout(lib)) == len(polys) + 9                     # the only top-level structure is found
+    lib.structures["CELL"].elements.append(LY.GdsElement("sref", sname="TOP", xy=np.array([[0, 0]])))
+    with pytest.raises((RecursionError, ValueError)):
+        LY.flattenLayout(lib, "TOP")                                         # a reference cycle
+    lib.structures["CELL"].elements[-1].sname = "NOWHERE"
+    with pytest.raises(KeyError):
+        LY.flattenLayout(lib, "TOP")
+
+
+def test_path_outline_shapes():
+    # an L-shaped Manhattan path: the mitre is the outer corner, the outline is a hexagon of area w * (len - w/2 ...) known in closed form
+    p = LY.pathOutline(np.array([[0, 0], [100, 0], [100, 60]]), 20, 0)
+    assert len(p) == 6
+    area = 0.5 * abs(np.sum(p[:, 0] * np.roll(p[:, 1], -1) - np.roll(p[:, 0], -1) * p[:, 1]))
+    assert area == pytest.approx(20 * 100 + 20 * 60)                        # two arms, the corner square counted once each side of the mitre
+    assert bbox(p) == (0, -10, 110, 60)
+    assert bbox(LY.pathOutline(np.array([[0, 0], [100, 0]]), 20, 2)) == (-10, -10, 110, 10)
+    assert bbox(LY.pathOutline(np.array([[0, 0], [100, 0]]), 20, 4, 5, 7)) == (-5, -10, 107, 10)
+    d = LY.pathOutline(np.array([[0, 0], [100, 100]]), 2 * np.sqrt(2.0), 0)  # a diagonal wire of half-width sqrt 2
+    assert sorted(map(tuple, d.round(9))) == sorted([(-1, 1), (1, -1), (99, 101), (101, 99)])
+    assert len(LY.pathOutline(np.array([[5, 5], [5, 5]]), 10, 0)) == 0       # no direction, no outline
+
+
+def test_raster_restatement_closed_forms():
+    # pixel centres at 0.5, 1.5, ...: a rectangle [2, 7) x [1, 4) covers columns 2..6, rows 1..3 exactly
+    e = LY.polygonEdges([rect(2, 1, 7, 4)])
+    g = LO.rasterize_edges(e, 10, 0.0, 0.0, 1.0)
+    want = np.zeros((10, 10), dtype=np.int16)
+    want[1:4, 2:7] = 1
+    assert np.array_equal(g, want)
+    # half-open edges: an edge THROUGH pixel centres -- left / bottom inside, right / top outside
+    g = LO.rasterize_edges(LY.polygonEdges([np.array([[2.5, 1.5], [6.5, 1.5], [6.5, 3.5], [2.5, 3.5]])]), 10, 0.0, 0.0, 1.0)
+    want[:] = 0
+    want[1:3, 2:6] = 1
+    assert np.array_equal(g, want)
+    # clockwise input is re-oriented, overlapping polygons are a union, a polygon beyond the window is clipped
+    polys = [rect(2, 1, 7, 4)[::-1], rect(5, 2, 9, 8), rect(-5, -5, 1, 1), rect(8, 8, 30, 30)]
+    g = LO.rasterize_edges(LY.polygonEdges(polys), 10, 0.0, 0.0, 1.0)
+    want[:] = 0
+    want[1:4, 2:7] = 1
+    want[2:8, 5:9] = 1
+    want[0:1, 0:1] = 1
+    want[8:10, 8:10] = 1
+    assert np.array_equal(g, want)
+    # a triangle: compare every centre with the independent point test, and the count with the area
+    tri = [np.array([[3.2, 2.1], [60.7, 10.4], [20.3, 55.9]])]
+    g = LO.rasterize_edges(LY.polygonEdges(tri), 64, 0.0, 0.0, 1.0)
+    for r in range(0, 64, 3):
+        for c in range(0, 64, 3):
+            assert bool(g[r, c]) == LO.point_in_polygons(tri, c + 0.5, r + 0.5), (r, c)
+    area = 0.5 * abs(np.sum(tri[0][:, 0] * np.roll(tri[0][:, 1], -1) - np.roll(tri[0][:, 0], -1) * tri[0][:, 1]))
+    assert abs(int(g.sum()) - area) < 0.03 * area
+    # a concave (U-shaped) polygon and a window with an offset origin and a 2.5 nm pixel
+    u = [np.array([[0, 0], [30, 0], [30, 30], [20, 30], [20, 10], [10, 10], [10, 30], [0, 30]], dtype=float)]
+    g = LO.rasterize_edges(LY.polygonEdges(u), 16, -5.0, -5.0, 2.5)
+    for r in range(16):
+        for c in range(16):
+            assert bool(g[r, c]) == LO.point_in_polygons(u, -5 + (c + 0.5) * 2.5, -5 + (r + 0.5) * 2.5), (r, c)
+    assert LO.rasterize_edges(np.zeros((0, 4)), 8, 0.0, 0.0, 1.0).sum() == 0

@@ -48,6 +48,12 @@ __global__ __launch_bounds__(256) void k_raster_edges(const double* __restrict__
     }
 }
 
+// (a kernel, not hipMemsetAsync: memset nodes of a captured HIP graph are not replayed correctly on this stack, see abbe_engine.hip)
+__global__ __launch_bounds__(256) void k_raster_clear(int* __restrict__ delta, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) delta[i] = 0;
+}
+
 __global__ __launch_bounds__(256) void k_raster_fill(const int* __restrict__ delta, int pn, int16_t* __restrict__ geo)
 {
     __shared__ int part[256];
@@ -91,7 +97,9 @@ int litho_rasterize_edges(const double* edges, int64_t n_edges, int pn, double x
         return LITHO_E_ARG;
     if (work_bytes < litho_rasterize_work_bytes(pn)) return LITHO_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemsetAsync(work, 0, litho_rasterize_work_bytes(pn), st));
+    const size_t nwork = (size_t)pn * (size_t)(pn + 1);
+    hipLaunchKernelGGL(k_raster_clear, dim3((unsigned)((nwork + 255) / 256 < 4096 ? (nwork + 255) / 256 : 4096)), dim3(256), 0, st, (int*)work, nwork);
+    HIP_TRY(hipGetLastError());
     if (n_edges > 0) {
         hipLaunchKernelGGL(k_raster_edges, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, st, edges, (int)n_edges, pn, x0, y0,
                            pixel, (int*)work);

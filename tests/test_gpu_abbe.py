@@ -564,6 +564,38 @@ def test_plan_cache_many_masks_one_optical_setting(L, dev):
     assert torch.equal(got, L.abbeImage(mk5, m5, pf5, bm5, PS, mk5.deltaK, WL, True, dev))
 
 
+def test_planned_call_is_capturable_in_a_hip_graph(L, dev):
+    """With a valid PlanCache the accumulate call launches no planning kernel and never waits for the stream, so the
+    whole abbeImage call can be captured into ONE HIP graph (torch.cuda.CUDAGraph) and replayed for mask after mask:
+    the replay gives the eager image bit for bit, also after the mask spectrum in the static input buffer changed."""
+    from lithographysimulator_amd.synthetic import bernoulli_mask, lines_mask
+    pn = 256
+    bm = L.LightSource(0.0, 0.5, pn, NA, device=dev).generateAnnular()
+    pf = L.Pupil(pn, WL, NA, f16(DEMO_AB), dev).generatePupilFunction()
+    m1, m2 = L.Mask(bernoulli_mask(pn), PS, dev), L.Mask(lines_mask(pn), PS, dev)
+    f1, f2 = m1.fraunhofer(WL, True), m2.fraunhofer(WL, True)
+    cache = L.PlanCache()
+    e1 = L.abbeImage(m1, f1, pf, bm, PS, m1.deltaK, WL, True, dev, plan_cache=cache)
+    e2 = L.abbeImage(m2, f2, pf, bm, PS, m2.deltaK, WL, True, dev, plan_cache=cache)
+    assert cache.valid
+    static = f1.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        L.abbeImage(m1, static, pf, bm, PS, m1.deltaK, WL, True, dev, plan_cache=cache)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = L.abbeImage(m1, static, pf, bm, PS, m1.deltaK, WL, True, dev, plan_cache=cache)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, e1)
+    static.copy_(f2)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, e2) and not torch.equal(e1, e2)
+
+
 @pytest.mark.parametrize("path", ["coarse", "direct"])
 def test_config2_full_source_vs_reference_golden(golden, L, dev, monkeypatch, path):
     """BASELINE config 2 IN FULL against the reference ITSELF (golden g11: the reference's own abbeImage over all 98,832

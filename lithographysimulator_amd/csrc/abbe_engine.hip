@@ -374,7 +374,7 @@ static int env_int(const char* name, int dflt)
 
 // Tuning / test knobs.  Read ONCE per C-ABI call (the parity tests flip them between calls), never per launch.
 struct Knobs {
-    int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk, xsplit, rect, xrect, coarse, gcombine, rowpairs;
+    int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk, xsplit, rect, xrect, coarse, gcombine, rowpairs, poison;
     static Knobs read()
     {
         Knobs k;
@@ -394,6 +394,7 @@ struct Knobs {
         k.coarse = env_int("LITHO_ABBE_COARSE", 1);
         k.gcombine = env_int("LITHO_ABBE_GCOMBINE", 1);
         k.rowpairs = env_int("LITHO_ABBE_ROWPAIRS", 0);
+        k.poison = env_int("LITHO_ABBE_POISON", 0);
         return k;
     }
 };
@@ -803,6 +804,13 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     if (!ops) return LITHO_E_ARG;
     const Knobs kn = Knobs::read();
 
+    if (kn.poison) {
+        // test knob: every scratch region starts the call as NaN bit patterns -- a kernel that reads scratch it (or an
+        // earlier launch of THIS call) has not written turns the image into NaN (tests/test_gpu_abbe.py)
+        unsigned char* lo = (unsigned char*)w.slab;
+        unsigned char* hi = (unsigned char*)w.T + w.t_bytes;
+        HIP_TRY(hipMemsetAsync(lo, 0xFF, (size_t)(hi - lo), st));
+    }
     hipLaunchKernelGGL(k_twiddle_table, dim3((N + 255) / 256), dim3(256), 0, st, w.twtab, N);
     int pl[PLAN_WORDS];
     const bool from_record = reuse && reuse->valid == 1 && reuse->pn == pn && reuse->N == N && reuse->planes == planes &&

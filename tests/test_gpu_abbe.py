@@ -564,6 +564,29 @@ def test_plan_cache_many_masks_one_optical_setting(L, dev):
     assert torch.equal(got, L.abbeImage(mk5, m5, pf5, bm5, PS, mk5.deltaK, WL, True, dev))
 
 
+@pytest.mark.parametrize("pn,mode", [(256, "direct"), (1024, "coarse"), (1024, "stack"), (512, "general"), (2048, "coarse")])
+def test_poisoned_scratch_changes_nothing(L, dev, monkeypatch, pn, mode):
+    """LITHO_ABBE_POISON=1 fills every scratch region of the workspace (slabs, coarse image, spectrum, Nyquist work area,
+    T) with NaN bit patterns at the start of the call: a kernel that read scratch which this call has not written would
+    turn the image into NaN.  The image must be bit-identical with and without."""
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    pf = L.Pupil(pn, WL, NA, f16(DEMO_AB), dev).generatePupilFunction()
+    if mode == "stack":
+        pf = L.throughFocusPupils(pn, WL, NA, f16(DEMO_AB), [-80.0, 0.0, 120.0], dev)
+    sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateAnnular(), pn)
+    K = 700 if pn <= 512 else 150 if pn == 1024 else 40
+    sel = sh[(torch.arange(K, device=dev) * sh.shape[0]) // K].contiguous()
+    env = {"LITHO_ABBE_COARSE": "2" if mode in ("coarse", "stack") else "0"}
+    if mode == "general":
+        env["LITHO_ABBE_FORCE_GENERAL"] = "1"
+    clean = _with_env(monkeypatch, L, env, lambda: L.abbeIntensity(mft, pf, sel, N).cpu())
+    dirty = _with_env(monkeypatch, L, dict(env, LITHO_ABBE_POISON="1"), lambda: L.abbeIntensity(mft, pf, sel, N).cpu())
+    assert bool(torch.isfinite(dirty).all()) and torch.equal(clean, dirty)
+
+
 def test_planned_call_is_capturable_in_a_hip_graph(L, dev):
     """With a valid PlanCache the accumulate call launches no planning kernel and never waits for the stream, so the
     whole abbeImage call can be captured into ONE HIP graph (torch.cuda.CUDAGraph) and replayed for mask after mask:

@@ -587,12 +587,13 @@ def test_poisoned_scratch_changes_nothing(L, dev, monkeypatch, pn, mode):
     assert bool(torch.isfinite(dirty).all()) and torch.equal(clean, dirty)
 
 
-def test_planned_call_is_capturable_in_a_hip_graph(L, dev):
+@pytest.mark.parametrize("pn", [256, 512])
+def test_planned_call_is_capturable_in_a_hip_graph(L, dev, pn):
     """With a valid PlanCache the accumulate call launches no planning kernel and never waits for the stream, so the
     whole abbeImage call can be captured into ONE HIP graph (torch.cuda.CUDAGraph) and replayed for mask after mask:
     the replay gives the eager image bit for bit, also after the mask spectrum in the static input buffer changed."""
+    from lithographysimulator_amd import _native as nat
     from lithographysimulator_amd.synthetic import bernoulli_mask, lines_mask
-    pn = 256
     bm = L.LightSource(0.0, 0.5, pn, NA, device=dev).generateAnnular()
     pf = L.Pupil(pn, WL, NA, f16(DEMO_AB), dev).generatePupilFunction()
     m1, m2 = L.Mask(bernoulli_mask(pn), PS, dev), L.Mask(lines_mask(pn), PS, dev)
@@ -600,7 +601,7 @@ def test_planned_call_is_capturable_in_a_hip_graph(L, dev):
     cache = L.PlanCache()
     e1 = L.abbeImage(m1, f1, pf, bm, PS, m1.deltaK, WL, True, dev, plan_cache=cache)
     e2 = L.abbeImage(m2, f2, pf, bm, PS, m2.deltaK, WL, True, dev, plan_cache=cache)
-    assert cache.valid
+    assert cache.valid and nat.last_plan()["coarse_grid"] == (1 if pn == 512 else 0)      # both evaluation paths
     static = f1.clone()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())

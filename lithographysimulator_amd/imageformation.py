@@ -161,6 +161,34 @@ def resistContour(raw, epsilon, threshold, dose=1.0, return_image=False):
     return (image, resist) if return_image else resist
 
 
+def bossungCurves(raw, epsilon, threshold, doses, pixelSize, row=None, column=None, exposed=False):
+    """Process-window table of a through-focus stack (the caller-side driver config 5 implies; the
+    reference has no such function -- its counterpart would be a loop over Pupil + abbeImage + a hand measurement):
+    critical dimension in nanometres [len(doses), planes] of the feature that crosses (row, column) of the
+    post-processed grid (default: its centre), measured along that row on the resist contour dose * image >= threshold
+    (one fused post-process + threshold pass per dose, every focal plane at once).  The feature is the run of UNEXPOSED
+    pixels through the point (a line of a dark-field line/space pattern; exposed=True: the run of exposed pixels, a space
+    or contact); 0 where the point is of the other kind.  `raw` = abbeIntensity of the stack, [planes, pn, pn]."""
+    if raw.dim() != 3:
+        raise ShapeError(f"bossungCurves takes the accumulated intensity of a stack [planes,pn,pn]; got {tuple(raw.shape)}")
+    table = []
+    for dose in doses:
+        contour = resistContour(raw, epsilon, threshold, dose=float(dose))          # uint8 [planes, n, n]
+        n = contour.shape[-1]
+        r = n // 2 if row is None else int(row)
+        c = n // 2 if column is None else int(column)
+        line = contour[:, r, :].to(torch.int32)                                     # [planes, n]
+        want = 1 if exposed else 0
+        same = (line == want)
+        # extent of the run of `want` pixels through column c: first differing pixel on either side
+        idx = torch.arange(n, device=line.device).expand_as(line)
+        left_stop = torch.where(~same & (idx < c), idx, torch.full_like(idx, -1)).max(dim=1).values
+        right_stop = torch.where(~same & (idx > c), idx, torch.full_like(idx, n)).min(dim=1).values
+        width = (right_stop - left_stop - 1).to(torch.float32) * float(pixelSize)
+        table.append(torch.where(same[:, c], width, torch.zeros_like(width)))
+    return torch.stack(table)
+
+
 def _all_reduce_sum(image, group):
     """ONE collective per image/stack.  RCCL ("nccl" backend on ROCm) reduces the device tensor in
     place over xGMI; a gloo group (CPU tests, or several ranks sharing one GPU) goes through a host copy."""

@@ -663,6 +663,72 @@ def test_config2_full_source_vs_reference_golden(golden, L, dev, monkeypatch, pa
         assert e_n < 1e-4
 
 
+@pytest.mark.parametrize("pn,skind,ab,limit", [(1024, "annular", [0, 0, 0, 0, 100], 0), (2048, "quasar", DEMO_AB, 0),
+                                               (4096, "annular", [0, 0, 0, 0, 100], 30000), (256, "circ", None, 0)])
+@pytest.mark.parametrize("path", ["coarse", "direct"])
+def test_few_beam_spectrum_closed_form_full_source(L, dev, monkeypatch, pn, skind, ab, limit, path):
+    """A known answer that needs no transform code at all, at the BASELINE sizes and FULL source lists: for a mask spectrum
+    of three isolated orders M = sum_t a_t delta(i_t, j_t), the reference's loop (imageformation.py:62-67 with the centred
+    transform of :32-45) gives
+        I[q, r] = sum_s sum_t |a_t P_t(s)|^2 + sum_{t<u} Re( C_tu exp(2 pi i ((i_t - i_u)(q - c) + (j_t - j_u)(r - c)) / N) ),
+        P_t(s) = P[(i_t - dy_s) mod pn, (j_t - dx_s) mod pn],   C_tu = 2 sum_s a_t P_t(s) conj(a_u P_u(s)),
+    three-beam interference fringes whose offset and complex contrasts are plain float64 sums over the source list.  First
+    pinned against the oracle's op chain on a small case, then every pixel of the GPU image is compared with it."""
+    from lithographysimulator_amd import _native as nat
+    monkeypatch.setenv("LITHO_ABBE_COARSE", "2" if path == "coarse" else "0")
+
+    def closed_form(P, shifts, orders, amps, pn, N):
+        P = P.cpu().to(torch.complex128).numpy()
+        sh = shifts.cpu().numpy().astype(np.int64)
+        c = pn // 2
+        Pt = [amps[t] * P[(orders[t][0] - sh[:, 0]) % pn, (orders[t][1] - sh[:, 1]) % pn] for t in range(len(orders))]
+        q = (np.arange(pn) - c).astype(np.float64)
+        img = np.full((pn, pn), sum(float(np.sum(np.abs(v) ** 2)) for v in Pt))
+        for t in range(len(orders)):
+            for u in range(t + 1, len(orders)):
+                C = 2.0 * np.sum(Pt[t] * np.conj(Pt[u]))
+                ph = np.exp(2j * np.pi * (orders[t][0] - orders[u][0]) * q / N)[:, None] * np.exp(2j * np.pi * (orders[t][1] - orders[u][1]) * q / N)[None, :]
+                img += (C * ph).real
+        return img
+
+    def spectrum(pn, orders, amps):
+        M = torch.zeros((pn, pn), dtype=torch.complex64)
+        for (i, j), a in zip(orders, amps):
+            M[i, j] = complex(a)
+        return M
+
+    amps = [1.0 + 0.5j, -0.75 + 0.25j, 0.3 - 1.1j]
+    # the formula against the oracle's op chain, small: 64^2, N = 128, 40 source points
+    o = O()
+    sp, sN = 64, 128
+    sorders = [(32 + 5, 32 - 3), (32 - 9, 32 + 7), (32 + 1, 32 + 12)]
+    sP = L.Pupil(sp, WL, NA, f16(DEMO_AB), dev).generatePupilFunction()
+    ssh = L.sourceShifts(L.LightSource(0.3, 0.8, sp, NA, device=dev).generateAnnular(), sp)[::7][:40].contiguous()
+    want_small = closed_form(sP, ssh, sorders, amps, sp, sN)
+    chain = o.abbe_raw(spectrum(sp, sorders, amps), sP.cpu(), ssh.cpu(), sN).numpy().astype(np.float64)
+    assert np.abs(chain - want_small).max() / want_small.max() < 2e-6
+
+    c = pn // 2
+    orders = [(c + pn // 57, c - pn // 170), (c - pn // 20, c + pn // 37), (c + pn // 300, c + pn // 11)]
+    mask = L.Mask(torch.zeros((pn, pn)), PS, dev)                  # only for the FFT sizing of this pixel size
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    P = L.Pupil(pn, WL, NA, None if ab is None else f16(ab), dev).generatePupilFunction()
+    ls = L.LightSource(0.0, 0.5, pn, NA, device=dev) if skind == "circ" else L.LightSource(0.4, 0.8, pn, NA, device=dev)
+    bm = ls.generateQuasar(4, -math.pi / 8) if skind == "quasar" else ls.generateAnnular()
+    sh = L.sourceShifts(bm, pn)
+    if limit:
+        sh = sh[(sh.shape[0] - limit) // 2:(sh.shape[0] - limit) // 2 + limit].contiguous()
+    got = L.abbeIntensity(spectrum(pn, orders, amps).to(dev), P, sh, N).cpu().numpy().astype(np.float64)
+    plan = nat.last_plan()
+    if path == "coarse" and sh.shape[0] >= 128:
+        assert plan["coarse_grid"] == 1, plan
+    want = closed_form(P, sh, orders, amps, pn, N)
+    e = np.abs(got - want).max() / want.max()
+    contrast = (want.max() - want.min()) / (want.max() + want.min())
+    print(f"{pn}^2, {sh.shape[0]} source points, {path}: three-beam closed form, fringe contrast {contrast:.3f}, max error rel-to-max {e:.2e}")
+    assert contrast > 0.05 and e < 3e-6
+
+
 def test_full_source_additivity_config2(L, dev):
     """BASELINE config 2 at its FULL source (S = 98,832): the image of all points == the sum of the images of 8
     contiguous balanced shards (exactly what 8 ranks accumulate before the all-reduce), and == the single-wait

@@ -663,6 +663,27 @@ def test_config2_full_source_vs_reference_golden(golden, L, dev, monkeypatch, pa
         assert e_n < 1e-4
 
 
+def few_beam_closed_form(P, shifts, orders, amps, pn, N):
+    P = P.cpu().to(torch.complex128).numpy()
+    sh = shifts.cpu().numpy().astype(np.int64)
+    c = pn // 2
+    Pt = [amps[t] * P[(orders[t][0] - sh[:, 0]) % pn, (orders[t][1] - sh[:, 1]) % pn] for t in range(len(orders))]
+    q = (np.arange(pn) - c).astype(np.float64)
+    img = np.full((pn, pn), sum(float(np.sum(np.abs(v) ** 2)) for v in Pt))
+    for t in range(len(orders)):
+        for u in range(t + 1, len(orders)):
+            C = 2.0 * np.sum(Pt[t] * np.conj(Pt[u]))
+            ph = np.exp(2j * np.pi * (orders[t][0] - orders[u][0]) * q / N)[:, None] * np.exp(2j * np.pi * (orders[t][1] - orders[u][1]) * q / N)[None, :]
+            img += (C * ph).real
+    return img
+
+def few_beam_spectrum(pn, orders, amps):
+    M = torch.zeros((pn, pn), dtype=torch.complex64)
+    for (i, j), a in zip(orders, amps):
+        M[i, j] = complex(a)
+    return M
+
+
 @pytest.mark.parametrize("pn,skind,ab,limit", [(1024, "annular", [0, 0, 0, 0, 100], 0), (2048, "quasar", DEMO_AB, 0),
                                                (4096, "annular", [0, 0, 0, 0, 100], 30000), (256, "circ", None, 0)])
 @pytest.mark.parametrize("path", ["coarse", "direct"])
@@ -677,26 +698,6 @@ def test_few_beam_spectrum_closed_form_full_source(L, dev, monkeypatch, pn, skin
     from lithographysimulator_amd import _native as nat
     monkeypatch.setenv("LITHO_ABBE_COARSE", "2" if path == "coarse" else "0")
 
-    def closed_form(P, shifts, orders, amps, pn, N):
-        P = P.cpu().to(torch.complex128).numpy()
-        sh = shifts.cpu().numpy().astype(np.int64)
-        c = pn // 2
-        Pt = [amps[t] * P[(orders[t][0] - sh[:, 0]) % pn, (orders[t][1] - sh[:, 1]) % pn] for t in range(len(orders))]
-        q = (np.arange(pn) - c).astype(np.float64)
-        img = np.full((pn, pn), sum(float(np.sum(np.abs(v) ** 2)) for v in Pt))
-        for t in range(len(orders)):
-            for u in range(t + 1, len(orders)):
-                C = 2.0 * np.sum(Pt[t] * np.conj(Pt[u]))
-                ph = np.exp(2j * np.pi * (orders[t][0] - orders[u][0]) * q / N)[:, None] * np.exp(2j * np.pi * (orders[t][1] - orders[u][1]) * q / N)[None, :]
-                img += (C * ph).real
-        return img
-
-    def spectrum(pn, orders, amps):
-        M = torch.zeros((pn, pn), dtype=torch.complex64)
-        for (i, j), a in zip(orders, amps):
-            M[i, j] = complex(a)
-        return M
-
     amps = [1.0 + 0.5j, -0.75 + 0.25j, 0.3 - 1.1j]
     # the formula against the oracle's op chain, small: 64^2, N = 128, 40 source points
     o = O()
@@ -704,8 +705,8 @@ def test_few_beam_spectrum_closed_form_full_source(L, dev, monkeypatch, pn, skin
     sorders = [(32 + 5, 32 - 3), (32 - 9, 32 + 7), (32 + 1, 32 + 12)]
     sP = L.Pupil(sp, WL, NA, f16(DEMO_AB), dev).generatePupilFunction()
     ssh = L.sourceShifts(L.LightSource(0.3, 0.8, sp, NA, device=dev).generateAnnular(), sp)[::7][:40].contiguous()
-    want_small = closed_form(sP, ssh, sorders, amps, sp, sN)
-    chain = o.abbe_raw(spectrum(sp, sorders, amps), sP.cpu(), ssh.cpu(), sN).numpy().astype(np.float64)
+    want_small = few_beam_closed_form(sP, ssh, sorders, amps, sp, sN)
+    chain = o.abbe_raw(few_beam_spectrum(sp, sorders, amps), sP.cpu(), ssh.cpu(), sN).numpy().astype(np.float64)
     assert np.abs(chain - want_small).max() / want_small.max() < 2e-6
 
     c = pn // 2
@@ -718,15 +719,49 @@ def test_few_beam_spectrum_closed_form_full_source(L, dev, monkeypatch, pn, skin
     sh = L.sourceShifts(bm, pn)
     if limit:
         sh = sh[(sh.shape[0] - limit) // 2:(sh.shape[0] - limit) // 2 + limit].contiguous()
-    got = L.abbeIntensity(spectrum(pn, orders, amps).to(dev), P, sh, N).cpu().numpy().astype(np.float64)
+    got = L.abbeIntensity(few_beam_spectrum(pn, orders, amps).to(dev), P, sh, N).cpu().numpy().astype(np.float64)
     plan = nat.last_plan()
     if path == "coarse" and sh.shape[0] >= 128:
         assert plan["coarse_grid"] == 1, plan
-    want = closed_form(P, sh, orders, amps, pn, N)
+    want = few_beam_closed_form(P, sh, orders, amps, pn, N)
     e = np.abs(got - want).max() / want.max()
     contrast = (want.max() - want.min()) / (want.max() + want.min())
     print(f"{pn}^2, {sh.shape[0]} source points, {path}: three-beam closed form, fringe contrast {contrast:.3f}, max error rel-to-max {e:.2e}")
     assert contrast > 0.05 and e < 3e-6
+
+
+def test_few_beam_closed_form_stack_and_wrapping_shifts(L, dev, monkeypatch):
+    """The same closed form for (a) config 5's shape: a through-focus stack at 2048^2 over the FULL quasar source, every
+    plane against its own fringes; (b) general mode: a source so wide that shifted pupil samples wrap around the grid
+    (the (i - dy) mod pn of the formula), 512^2."""
+    from lithographysimulator_amd import _native as nat
+    amps = [0.9 - 0.2j, 0.4 + 0.8j, -0.6 + 0.1j]
+    pn = 2048
+    c = pn // 2
+    orders = [(c + 31, c - 77), (c - 140, c + 9), (c + 3, c + 160)]
+    eps, N = L.Mask(torch.zeros((pn, pn)), PS, dev).calculateEpsilonN(4 / pn, PS, WL)
+    stack = L.throughFocusPupils(pn, WL, NA, f16(DEMO_AB), [-200.0, 35.0, 260.0], dev)
+    sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateQuasar(4, -math.pi / 8), pn)
+    got = L.abbeIntensity(few_beam_spectrum(pn, orders, amps).to(dev), stack, sh, N).cpu().numpy().astype(np.float64)
+    assert nat.last_plan()["coarse_grid"] == 1 and got.shape == (3, pn, pn)
+    for p in range(3):
+        want = few_beam_closed_form(stack[p], sh, orders, amps, pn, N)
+        e = np.abs(got[p] - want).max() / want.max()
+        print(f"2048^2 x 3 planes, {sh.shape[0]} source points, plane {p}: three-beam closed form, max error rel-to-max {e:.2e}")
+        assert e < 3e-6
+    assert np.abs(got[0] - got[2]).max() / got[0].max() > 1e-2          # the planes differ
+    pn = 512
+    c = pn // 2
+    orders = [(c + 11, c - 20), (c - 60, c + 3), (c + 2, c + 70)]
+    eps, N = L.Mask(torch.zeros((pn, pn)), PS, dev).calculateEpsilonN(4 / pn, PS, WL)
+    P = L.Pupil(pn, WL, NA, f16(DEMO_AB), dev).generatePupilFunction()
+    sh = L.sourceShifts(L.LightSource(1.2, 1.9, pn, NA, device=dev).generateAnnular(), pn)[::5].contiguous()
+    got = L.abbeIntensity(few_beam_spectrum(pn, orders, amps).to(dev), P, sh, N).cpu().numpy().astype(np.float64)
+    assert nat.last_plan()["general"] == 1, nat.last_plan()
+    want = few_beam_closed_form(P, sh, orders, amps, pn, N)
+    e = np.abs(got - want).max() / max(want.max(), 1e-30)
+    print(f"512^2 general mode (wrapping shifts), {sh.shape[0]} source points: closed form, max error rel-to-max {e:.2e}")
+    assert want.max() > 0 and e < 3e-6
 
 
 def test_full_source_additivity_config2(L, dev):

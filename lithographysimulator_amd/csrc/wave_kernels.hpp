@@ -205,16 +205,18 @@ __global__ __launch_bounds__(WaveShape<LOG2N>::THREADS, WaveShape<LOG2N>::MINWAV
 
 // ----------------------------------------------------------------------------------
 // y-pass for the 4096-point coarse-grid transform (N = pn = 4096: BASELINE config 4) over 16-COLUMN T tiles.  At 4096^2 a
-// T item is 67 MB: T streams through HBM, where the x-pass's stores are bound by their granule -- 64-byte granules
-// (8-column tiles) 21.6 us per item, whole 128-byte lines (16-column tiles) 14.2 -- but a wave that owns one column uses
-// 8 bytes of every 128-byte row (k_ypass_wave over 16-column tiles: 21.2 -> 28.8 us per item).  Here the NW = 4 (or 8) waves of a
-// workgroup own NW adjacent columns = 8 NW bytes of every tile row, and load them cooperatively: wave w fetches that part of
-// the rows of the live slots w, w + NW, ... with NW/2 16-byte loads per lane (64 consecutive rows per instruction) and deals
-// the NW columns out to the NW waves' staging areas --
-// their transpose matrices, idle at that point.  After a barrier every wave reads its 33 live samples back with
-// compile-time slot indices and runs the same transform as k_ypass_wave<12, ., true>.  Two workgroup barriers per line
-// (like the pair-loading kernel).  NW = 4: 76 KB of LDS, two workgroups per CU that hide each other's loads; NW = 8 (143 KB,
-// one workgroup per CU, every sector requested once) leaves the load latency exposed: 44 us per item.
+// T item is 67 MB: T streams through HBM, and there the x-pass depends on how a line of T is stored -- 8-column tiles
+// (two rows per 128-byte line) 21.6 us per item, 16-column tiles (a store instruction covers whole lines) 14.0 -- but a wave
+// that owns one column uses 8 bytes of every 128-byte row (k_ypass_wave over 16-column tiles: 21.2 -> 28.8 us per item).
+// Here the four waves of a workgroup own four adjacent columns = 32 bytes of every tile row and load them TOGETHER: the
+// line's 33 live slots x 64 rows are 66 units of 32 rows; wave w takes the units w, w + 4, ... -- two lanes per row, 16 bytes
+// per lane, 32 rows per load instruction, 17 loads per wave -- and every lane deals its two columns into the staging areas
+// of the waves that own them (the transpose matrices, idle at that point).  After a barrier every wave reads its 33 live
+// samples back and runs the transform of k_ypass_wave<12, ., true>, with the lane-twiddle table read AFTER pass A.  Two
+// workgroup barriers per line; 76 KB of LDS, two workgroups per CU.  Measured steps (us per item): 64 rows x 32 bytes per
+// instruction with hoisted (spilled) offsets 38.9, literal offsets 33.3, two lanes per row 29.5, no accumulator spills
+// (1.3 GB of scratch writes per launch before) 24.4.  An eight-wave variant (64 bytes of the row, one 143 KB workgroup per
+// CU) left the load latency exposed: 44.  profiles/r03_slab4096_probe.txt.
 // ----------------------------------------------------------------------------------
 template <int NW>
 struct CoopShape {

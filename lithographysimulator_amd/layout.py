@@ -322,32 +322,44 @@ def flattenLayout(lib: GdsLibrary, top: Optional[str] = None, layers: Optional[S
                 if e.kind == "sref":
                     walk(e.sname, m @ t, p[0] @ m.T + o, depth + 1)
                 else:
+                    # the referenced cell is flattened ONCE (at the array's origin) and its polygons are translated to
+                    # the cols x rows lattice points: a 1000 x 1000 array costs one recursion, not a million
                     dc, dr = (p[1] - p[0]) / max(e.cols, 1), (p[2] - p[0]) / max(e.rows, 1)
-                    for j in range(e.rows):
-                        for i in range(e.cols):
-                            walk(e.sname, m @ t, (p[0] + i * dc + j * dr) @ m.T + o, depth + 1)
+                    first = len(out)
+                    walk(e.sname, m @ t, p[0] @ m.T + o, depth + 1)
+                    cell = out[first:]
+                    del out[first:]
+                    ii, jj = np.meshgrid(np.arange(e.cols), np.arange(e.rows), indexing="xy")
+                    offs = (ii.reshape(-1, 1) * dc + jj.reshape(-1, 1) * dr) @ m.T          # [cols * rows, 2], row-major in j
+                    for q in cell:
+                        out.extend(list(q[None, :, :] + offs[:, None, :]))
 
     walk(top, np.eye(2), np.zeros(2), 0)
-    polys = []
-    for q in out:
-        q = q * nm
-        area2 = float(np.sum(q[:, 0] * np.roll(q[:, 1], -1) - np.roll(q[:, 0], -1) * q[:, 1]))
-        polys.append(q[::-1].copy() if area2 < 0 else q)        # a reflection turns polygons clockwise
-    return polys
+    return [q for batch in _oriented_batches(out, nm) for q in batch]
+
+
+def _oriented_batches(polygons, scale=1.0):
+    """The polygons made counter-clockwise (a reflection turns them clockwise) and scaled, as [n, k, 2] arrays grouped
+    by vertex count k (in order of first appearance): layouts are millions of rectangles, not a Python loop over them."""
+    groups: Dict[int, List[np.ndarray]] = {}
+    for q in polygons:
+        q = np.asarray(q, dtype=np.float64).reshape(-1, 2)
+        if len(q) >= 3:
+            groups.setdefault(len(q), []).append(q)
+    batches = []
+    for k, items in groups.items():
+        a = np.stack(items) * scale
+        area2 = np.sum(a[:, :, 0] * np.roll(a[:, :, 1], -1, axis=1) - np.roll(a[:, :, 0], -1, axis=1) * a[:, :, 1], axis=1)
+        cw = area2 < 0
+        a[cw] = a[cw, ::-1]
+        batches.append(a)
+    return batches
 
 
 def polygonEdges(polygons: Sequence[np.ndarray]) -> np.ndarray:
     """[n_edges, 4] float64 (x0, y0, x1, y1) of the closed polygons, every polygon made counter-clockwise first (so that
     overlapping polygons add winding numbers of the same sign: the raster is their UNION)."""
-    rows = []
-    for q in polygons:
-        q = np.asarray(q, dtype=np.float64).reshape(-1, 2)
-        if len(q) < 3:
-            continue
-        area2 = float(np.sum(q[:, 0] * np.roll(q[:, 1], -1) - np.roll(q[:, 0], -1) * q[:, 1]))
-        if area2 < 0:
-            q = q[::-1]
-        rows.append(np.concatenate([q, np.roll(q, -1, axis=0)], axis=1))
+    rows = [np.concatenate([a, np.roll(a, -1, axis=1)], axis=2).reshape(-1, 4) for a in _oriented_batches(polygons)]
     return np.ascontiguousarray(np.concatenate(rows, axis=0)) if rows else np.zeros((0, 4))
 
 

@@ -151,3 +151,32 @@ def test_raster_restatement_closed_forms():
         for c in range(16):
             assert bool(g[r, c]) == LO.point_in_polygons(u, -5 + (c + 0.5) * 2.5, -5 + (r + 0.5) * 2.5), (r, c)
     assert LO.rasterize_edges(np.zeros((0, 4)), 8, 0.0, 0.0, 1.0).sum() == 0
+
+
+def test_reader_skips_text_nodes_and_properties():
+    """Elements and records a mask raster has no use for (TEXT, NODE, PROPATTR / PROPVALUE, ELFLAGS, PLEX) are stepped over
+    record by record without disturbing the neighbours."""
+    import struct
+    rec = LY._rec
+    xy = lambda pts: struct.pack(">%di" % (2 * len(pts)), *[v for p in pts for v in p])
+    stamp = struct.pack(">12h", *([2026, 1, 1, 0, 0, 0] * 2))
+    sq = [(0, 0), (40, 0), (40, 40), (0, 40), (0, 0)]
+    blob = b"".join([
+        rec(LY.HEADER, LY.DT_INT2, struct.pack(">h", 600)), rec(LY.BGNLIB, LY.DT_INT2, stamp), rec(LY.LIBNAME, LY.DT_ASCII, b"L"),
+        rec(LY.UNITS, LY.DT_REAL8, bytes.fromhex("3e4189374bc6a7ef3944b82fa09b5a51")),
+        rec(LY.BGNSTR, LY.DT_INT2, stamp), rec(LY.STRNAME, LY.DT_ASCII, b"TOP"),
+        rec(LY.TEXT, LY.DT_NONE), rec(LY.LAYER, LY.DT_INT2, struct.pack(">h", 63)), rec(0x16, LY.DT_INT2, struct.pack(">h", 0)),
+        rec(0x17, LY.DT_BITS, b"\x00\x05"), rec(LY.STRANS, LY.DT_BITS, b"\x80\x00"), rec(LY.MAG, LY.DT_REAL8, LY.real8_encode(3.0)),
+        rec(LY.XY, LY.DT_INT4, xy([(5, 5)])), rec(0x19, LY.DT_ASCII, b"label"), rec(LY.ENDEL, LY.DT_NONE),
+        rec(LY.BOUNDARY, LY.DT_NONE), rec(0x26, LY.DT_BITS, b"\x00\x01"), rec(0x2F, LY.DT_INT4, struct.pack(">i", 7)),
+        rec(LY.LAYER, LY.DT_INT2, struct.pack(">h", 4)), rec(LY.DATATYPE, LY.DT_INT2, struct.pack(">h", 2)), rec(LY.XY, LY.DT_INT4, xy(sq)),
+        rec(0x2B, LY.DT_INT2, struct.pack(">h", 1)), rec(0x2C, LY.DT_ASCII, b"net_a"), rec(LY.ENDEL, LY.DT_NONE),
+        rec(LY.NODE, LY.DT_NONE), rec(LY.LAYER, LY.DT_INT2, struct.pack(">h", 9)), rec(0x2A, LY.DT_INT2, struct.pack(">h", 0)),
+        rec(LY.XY, LY.DT_INT4, xy([(1, 1), (2, 2)])), rec(LY.ENDEL, LY.DT_NONE),
+        rec(LY.ENDSTR, LY.DT_NONE), rec(LY.ENDLIB, LY.DT_NONE)])
+    lib = LY.readGDSII(blob)
+    els = lib.structures["TOP"].elements
+    assert len(els) == 1 and els[0].kind == "boundary" and (els[0].layer, els[0].datatype) == (4, 2)
+    assert els[0].transform.reflect is False and els[0].transform.mag == 1.0          # the TEXT's STRANS / MAG did not leak
+    polys = LY.flattenLayout(lib)
+    assert len(polys) == 1 and bbox(polys[0]) == (0, 0, 40, 40)

@@ -397,7 +397,10 @@ def main():
     eff40 = 40.0 * pn * pn * prof["ypass_points"] / (both_ms * 1e-3) / 1e9 if both_ms else 0.0
     dom_s = kern[dom]["avg_launch_ms"] * 1e-3
     fabric_gbs = traffic / dom_s / 1e9 if traffic and dom_s > 0 else None
-    roofline = {"bound": "valu", "kernel": kern[dom]["kernel"],
+    # "bound" takes the contract's two values ("hbm" | "mfma"): this is the flop side -- priced against the dense fp32 peak,
+    # 157.3 TFLOP/s, which on gfx950 is the same figure for the matrix and the vector pipe; `bound_detail` says which pipe
+    roofline = {"bound": "mfma", "bound_detail": "fp32 vector (VALU) issue: the path has no MFMA work; dense fp32 peak of the vector pipe = of "
+                                                  "the matrix pipe = 157.3 TFLOP/s", "kernel": kern[dom]["kernel"],
                 "achieved": kern[dom]["achieved_TFLOPs"], "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": kern[dom]["achieved_TFLOPs"] / VALU_PEAK_TFLOPS, "traffic": traffic,
                 "avg_launch_ms": kern[dom]["avg_launch_ms"],

@@ -28,7 +28,8 @@ def test_bench_json_contract():
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in rl, key
     # the bound is the measured limiter (fp32 VALU issue), and a roofline fraction can never exceed 1
-    assert rl["bound"] == "valu" and rl["unit"] == "TFLOP/s" and rl["peak"] == 157.3
+    assert rl["bound"] in ("hbm", "mfma") and rl["bound"] == "mfma" and "VALU" in rl["bound_detail"]
+    assert rl["unit"] == "TFLOP/s" and rl["peak"] == 157.3
     assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-9 and 0 < rl["frac"] <= 1
     assert 0 < rl["pipeline"]["frac"] <= 1
     # the memory-side view: top-level keys, labelled for what they are (L2 <-> fabric requests, Infinity-Cache hits included)

@@ -85,18 +85,29 @@ __device__ __forceinline__ float2 buf_load_c64(__amdgpu_buffer_rsrc_t r, unsigne
     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
     return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
 }
+// Cache policy of the T stores (buffer aux bits: sc0 = 1, nt = 2, sc1 = 16).  With sc1 the L2 writes T through instead of
+// keeping dirty lines nobody on its XCD will ask for again (the y-pass reads T through other L2s).  Same-box A/B, sc1 against
+// none: config 3 (2048^2) 309.0 vs 322.3 ms per 36,000 points (x-pass 49.9 vs 54.8 us per launch, y-pass unchanged), config 4
+// 208.0 vs 211.3; config 2 (1024^2) 195.2 vs 193.4 and config 1 equal -- so: from 2048-point rows up.  sc0 alone changes
+// nothing, nt costs 18 %.  profiles/r03_xstore_policy.txt.  LITHO_XSTORE_AUX overrides the bits of the large sizes.
+#ifndef LITHO_XSTORE_AUX
+#define LITHO_XSTORE_AUX 16
+#endif
+template <int LOG2N> inline constexpr int t_store_aux = LOG2N >= 11 ? LITHO_XSTORE_AUX : 0;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int AUX = 0>
 __device__ __forceinline__ void buf_store_c64x2(__amdgpu_buffer_rsrc_t r, unsigned off, float2 a, float2 b) {
     u32x4 w;
     w.x = __float_as_uint(a.x); w.y = __float_as_uint(a.y);
     w.z = __float_as_uint(b.x); w.w = __float_as_uint(b.y);
-    __builtin_amdgcn_raw_buffer_store_b128(w, r, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(w, r, off, 0, AUX);
 }
+template <int AUX = 0>
 __device__ __forceinline__ void buf_store_c64(__amdgpu_buffer_rsrc_t r, unsigned off, float2 v) {
     u32x2 w;
     w.x = __float_as_uint(v.x);
     w.y = __float_as_uint(v.y);
-    __builtin_amdgcn_raw_buffer_store_b64(w, r, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(w, r, off, 0, AUX);
 }
 
 // float2 offset of (row a, column q) inside one source point's T block
@@ -277,11 +288,11 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, (RP == 2 ? Launch<LOG2N>::W
                                 if (active) {
                                     const float bx = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x[m].x), 0x128, 0xF, 0xF, false));   // row_ror:8
                                     const float by = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x[m].y), 0x128, 0xF, 0xF, false));
-                                    buf_store_c64(rT, toff[m] + offc, hi8 ? make_float2(bx, by) : held[m]);
-                                    buf_store_c64(rT, toff[m] + offd, hi8 ? held[m] : make_float2(bx, by));
+                                    buf_store_c64<t_store_aux<LOG2N>>(rT, toff[m] + offc, hi8 ? make_float2(bx, by) : held[m]);
+                                    buf_store_c64<t_store_aux<LOG2N>>(rT, toff[m] + offd, hi8 ? held[m] : make_float2(bx, by));
                                 }
                             } else {
-                                buf_store_c64(rT, toff[m], x[m]);
+                                buf_store_c64<t_store_aux<LOG2N>>(rT, toff[m], x[m]);
                             }
                         }
 #endif
@@ -381,7 +392,7 @@ __global__ __launch_bounds__(Launch<LOG2N - 1>::THREADS, Launch<LOG2N - 1>::WAVE
             make_rsrc(Tbuf + (size_t)s * g.t_point, (size_t)g.t_point * sizeof(float2));
         static_for<0, 16>([&](auto m_) {
             constexpr int m = decltype(m_)::value;
-            if constexpr ((OUT >> m) & 1u) buf_store_c64x2(rT, toff[m], even[m], x[m]);
+            if constexpr ((OUT >> m) & 1u) buf_store_c64x2<t_store_aux<LOG2N>>(rT, toff[m], even[m], x[m]);
         });
     }
 }

@@ -60,6 +60,10 @@ static inline int wave_grid_x(int pn)
 }
 
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+// cache-policy bits of k_ypass_rect's T loads (build-time experiment hook: sc0 = 1, nt = 2, sc1 = 16)
+#ifndef LITHO_YLOAD_AUX
+#define LITHO_YLOAD_AUX 0
+#endif
 
 // FULL = false: N = 2 pn (half of the bins are kept, a quarter of the inputs live).  FULL = true: N = pn -- the
 // "coarse grid" transform (every bin kept, half of the inputs live; D = 1 only), see k_ypass_rect.
@@ -471,7 +475,7 @@ __global__ __launch_bounds__(256 * GW, 2) void k_ypass_rect(
             static_for<0, NL / 2>([&](auto q_) {
                 constexpr int q = decltype(q_)::value;
                 if constexpr (j <= JL || j >= H - JL) {
-                    const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(rTs[q / QT], slot_off(j) + 16u * (q % QT), 0, 0);
+                    const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(rTs[q / QT], slot_off(j) + 16u * (q % QT), 0, LITHO_YLOAD_AUX);
                     x[(2 * q) * H + j] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));          // column qx0 + 2q
                     x[(2 * q + 1) * H + j] = make_float2(__uint_as_float(v.z), __uint_as_float(v.w));      // column qx0 + 2q + 1
                 } else {

@@ -132,6 +132,8 @@ __device__ __forceinline__ void diag_keep(float2 v, unsigned o) { asm volatile("
 // the two rows' stores merely interleaved 19.8, half-wave by half-wave (v_permlane32_swap) 20.6, blended 19.6 -- against
 // 14.0 for one row per workgroup on 16-column tiles, which is what the planner picks there.  Costs a second pupil row and
 // a held output row in registers: two workgroups per CU instead of three.
+// (Those figures are with plain stores; since the T stores carry sc1 -- no write-allocate fetch -- one row per workgroup on
+// 8-column tiles takes 19.6 us per item itself and the pairs 19.8: the knob stays as a parity-tested variant, nothing more.)
 template <int LOG2N, int RL, bool PRUNED, int NP, int RP = 1>
 __global__ __launch_bounds__(Launch<LOG2N>::THREADS, (RP == 2 ? Launch<LOG2N>::WAVES / Launch<LOG2N>::WG_PER_CU * 2 : Launch<LOG2N>::WAVES)) void k_xpass_abbe(
     const float2* __restrict__ P, const float2* __restrict__ M, const int* __restrict__ shifts,

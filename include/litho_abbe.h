@@ -122,6 +122,30 @@ int litho_abbe_accumulate_planned(const void *maskFT, const void *pupil, int pla
                                   int pn, int N, float *out, void *workspace, size_t workspace_bytes,
                                   void *stream, litho_abbe_plan *plan, int64_t *count_host);
 
+/* ---- The same call with the launch planner's options passed explicitly instead of through the process environment.
+ * The reference has no counterpart (its loop has nothing to tune, imageformation.py:62-67); this is how tests, bench.py
+ * and embedding applications select an evaluation path per CALL -- per thread, per stream -- without touching
+ * LITHO_ABBE_* variables.  Every field: < 0 = not set (the LITHO_ABBE_<NAME> environment variable if present, else the
+ * default); the meanings are those of DESIGN.md section 8.  `size` = sizeof(litho_abbe_options) as the caller compiled it
+ * (fields beyond it count as not set, so the struct can grow).  plan, options, count_dev and count_host may each be NULL
+ * (count_dev NULL: `capacity` is the number of source points). */
+typedef struct litho_abbe_options {
+    int32_t size;
+    int32_t coarse;          /* 0 direct path, 1 coarse grid when the source list repays it (default), 2 whenever eligible */
+    int32_t batch;           /* source points per launch pair (0 = automatic) */
+    int32_t groups;          /* y-pass groups (partial-image slabs) per launch (0 = automatic) */
+    int32_t xchunk;          /* source points per x-pass workgroup (0 = automatic) */
+    int32_t tile;            /* T tile width in columns: 4, 8, 16 (0 = automatic) */
+    int32_t plane_chunk;     /* planes of a stack in flight per launch pair (0 = automatic: 1) */
+    int32_t w64, rect, w64_8192, xsplit, xrect, w64x, gcombine, rowpairs;   /* kernel families, DESIGN.md section 8 */
+    int32_t force_generic, force_general;                                  /* runtime-predicated kernels / modular gather */
+    int32_t poison;          /* 1: scratch starts the call as NaN bit patterns (tests) */
+} litho_abbe_options;
+int litho_abbe_accumulate_opts(const void *maskFT, const void *pupil, int planes, const int32_t *shifts,
+                               const int32_t *count_dev, int64_t capacity, int pn, int N, float *out,
+                               void *workspace, size_t workspace_bytes, void *stream, litho_abbe_plan *plan,
+                               const litho_abbe_options *options, int64_t *count_host);
+
 /* ---- Single-point field: calculateFFTAerial(pf, maskFFFT, pixelNumber, N)
  * (imageformation.py:32-45).  field = complex64 [pn,pn].  Reads back 16 bytes. */
 int litho_abbe_field(const void *pf, const void *maskFT, int pn, int N, void *field,

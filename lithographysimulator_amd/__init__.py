@@ -2,6 +2,7 @@
 quarterwave0/LithographySimulator (Mask / LightSource / Pupil / abbeImage)."""
 from .imageformation import (PlanCache, abbeImage, abbeIntensity, bossungCurves, calculateFFTAerial,   # noqa: F401
                              postProcess, resistContour)
+from ._native import engineOptions                                                      # noqa: F401
 from .layout import (GdsLibrary, flattenLayout, maskFromGDSII, rasterizeLayout, readGDSII,  # noqa: F401
                      writeGDSII)
 from .lightsource import LightSource, sourceShifts, sourceShiftsAsync                                      # noqa: F401
@@ -9,6 +10,6 @@ from .mask import Mask                                                          
 from .pupil import (OSAindexToMN, Pupil, generatePhi, generateWavefrontError,           # noqa: F401
                     generateZ, throughFocusPupils)
 
-__all__ = ["Mask", "LightSource", "Pupil", "abbeImage", "abbeIntensity", "calculateFFTAerial", "postProcess", "resistContour", "bossungCurves", "PlanCache",
+__all__ = ["Mask", "LightSource", "Pupil", "abbeImage", "abbeIntensity", "calculateFFTAerial", "postProcess", "resistContour", "bossungCurves", "PlanCache", "engineOptions",
            "sourceShifts", "sourceShiftsAsync", "OSAindexToMN", "generateWavefrontError", "generatePhi", "generateZ",
            "throughFocusPupils", "readGDSII", "writeGDSII", "flattenLayout", "rasterizeLayout", "maskFromGDSII", "GdsLibrary"]

@@ -2,8 +2,10 @@
 
 The HIP library is the product: if it is missing, or no HIP device is visible, every
 compute entry point raises -- there is no CPU fallback."""
+import contextlib
 import ctypes
 import os
+import threading
 from ctypes import POINTER, c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
 
 import torch
@@ -31,6 +33,8 @@ _SIGNATURES = {
                                               c_void_p, c_void_p, c_size_t, c_void_p, POINTER(c_int64)]),
     "litho_abbe_accumulate_planned": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int,
                                               c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, POINTER(c_int64)]),
+    "litho_abbe_accumulate_opts": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                           c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, POINTER(c_int64)]),
     "litho_abbe_field": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "litho_postprocess_size": (c_int, [c_int, c_double, POINTER(c_int)]),
     "litho_postprocess": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p]),
@@ -120,18 +124,31 @@ def ptr(t):
 
 
 _workspaces = {}
+WORKSPACE_CACHE_BYTES = 8 << 30      # the cache keeps at most this much per device (one entry always stays)
 
 
 def workspace(device, pn, N):
-    """Scratch buffer for the Abbe / field / mask-spectrum calls, cached per (device, pn, N)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), pn, N)
-    ws = _workspaces.get(key)
+    """Scratch buffer for the Abbe / field / mask-spectrum calls, cached per (device, pn, N): 0.3 GiB at 256^2 ..
+    1.3 GiB at 2048^2, 4.6 GiB from 4096^2 up (litho_abbe_workspace_bytes).
+
+    Lifetime: the cache only DROPS ITS OWN REFERENCE when it evicts an entry (least recently used first, once a device's
+    entries exceed WORKSPACE_CACHE_BYTES) -- a workspace that a PlanCache holds (and therefore every HIP graph captured
+    through that PlanCache, whose kernels carry the raw pointer) stays allocated for as long as the PlanCache lives.
+    Entries of other devices are never touched."""
+    dev_index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (dev_index, pn, N)
+    ws = _workspaces.pop(key, None)
     if ws is None:
         nbytes = c_size_t(0)
         check(lib().litho_abbe_workspace_bytes(pn, N, ctypes.byref(nbytes)), "litho_abbe_workspace_bytes")
-        _workspaces.clear()                       # keep one live workspace: they are up to ~1.5 GiB
+        mine = [k for k in _workspaces if k[0] == dev_index]                   # insertion order = least recently used first
+        held = sum(_workspaces[k].numel() for k in mine)
+        for k in mine:
+            if held + nbytes.value <= WORKSPACE_CACHE_BYTES:
+                break
+            held -= _workspaces.pop(k).numel()
         ws = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
-        _workspaces[key] = ws
+    _workspaces[key] = ws                                                      # (re)insert as most recently used
     return ws
 
 
@@ -146,6 +163,55 @@ class PlanRecord(ctypes.Structure):
     """litho_abbe_plan (include/litho_abbe.h)."""
     _fields_ = [("words", ctypes.c_int32 * 16), ("valid", ctypes.c_int32), ("pn", ctypes.c_int32),
                 ("N", ctypes.c_int32), ("planes", ctypes.c_int32)]
+
+
+class Options(ctypes.Structure):
+    """litho_abbe_options (include/litho_abbe.h): per-call launch-planner options; -1 = not set."""
+    _names = ("coarse", "batch", "groups", "xchunk", "tile", "plane_chunk", "w64", "rect", "w64_8192", "xsplit", "xrect",
+              "w64x", "gcombine", "rowpairs", "force_generic", "force_general", "poison")
+    _fields_ = [("size", ctypes.c_int32)] + [(n, ctypes.c_int32) for n in _names]
+
+    @classmethod
+    def make(cls, mapping):
+        o = cls()
+        o.size = ctypes.sizeof(cls)
+        for n in cls._names:
+            setattr(o, n, -1)
+        for k, v in (mapping or {}).items():
+            if k not in cls._names:
+                raise KeyError(f"unknown engine option {k!r}; known: {', '.join(cls._names)}")
+            setattr(o, k, int(v))
+        return o
+
+
+_option_stack = threading.local()
+
+
+@contextlib.contextmanager
+def engineOptions(**kw):
+    """`with engineOptions(coarse=2, batch=7): ...` -- launch-planner options for every Abbe call of THIS thread inside the
+    block (nested blocks merge, inner wins), passed through the C ABI's litho_abbe_options; nothing touches os.environ.
+    Names = the LITHO_ABBE_* variables of DESIGN.md section 8 in lower case."""
+    Options.make(kw)                                       # validate the names now
+    stack = getattr(_option_stack, "v", None)
+    if stack is None:
+        stack = _option_stack.v = []
+    stack.append(kw)
+    try:
+        yield
+    finally:
+        stack.pop()
+
+
+def current_options(extra=None):
+    """Options record for a call: the enclosing engineOptions blocks merged with the call's own `options=` mapping; None
+    when nothing is set (the library then reads the environment, as before)."""
+    merged = {}
+    for kw in getattr(_option_stack, "v", None) or ():
+        merged.update(kw)
+    if extra:
+        merged.update(extra)
+    return Options.make(merged) if merged else None
 
 
 def last_plan():

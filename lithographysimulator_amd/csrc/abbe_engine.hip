@@ -24,6 +24,7 @@
 
 #include <climits>
 #include <cmath>
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -372,29 +373,40 @@ static int env_int(const char* name, int dflt)
     return (e && *e) ? atoi(e) : dflt;
 }
 
-// Tuning / test knobs.  Read ONCE per C-ABI call (the parity tests flip them between calls), never per launch.
+// Tuning / test knobs.  Resolved ONCE per C-ABI call, never per launch: a field of the caller's litho_abbe_options that is
+// >= 0 wins, otherwise the LITHO_ABBE_* environment variable, otherwise the default.
 struct Knobs {
     int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk, xsplit, rect, xrect, coarse, gcombine, rowpairs, poison;
-    static Knobs read()
+    static int pick(const litho_abbe_options* o, size_t off, const char* name, int dflt)
     {
+        if (o && off + sizeof(int32_t) <= (size_t)o->size) {
+            const int32_t v = *(const int32_t*)((const unsigned char*)o + off);
+            if (v >= 0) return v;
+        }
+        return env_int(name, dflt);
+    }
+    static Knobs read(const litho_abbe_options* o)
+    {
+#define LITHO_KNOB(field, name, dflt) k.field = pick(o, offsetof(litho_abbe_options, field), name, dflt)
         Knobs k;
-        k.force_generic = env_int("LITHO_ABBE_FORCE_GENERIC", 0);
-        k.force_general = env_int("LITHO_ABBE_FORCE_GENERAL", 0);
-        k.groups = env_int("LITHO_ABBE_GROUPS", 0);
-        k.batch = env_int("LITHO_ABBE_BATCH", 0);
-        k.xchunk = env_int("LITHO_ABBE_XCHUNK", 0);
-        k.tile = env_int("LITHO_ABBE_TILE", 0);          // 0 = automatic (8 columns on the wave-kernel path, else 4)
-        k.w64 = env_int("LITHO_ABBE_W64", 1);
-        k.w64_8192 = env_int("LITHO_ABBE_W64_8192", 1);
-        k.w64x = env_int("LITHO_ABBE_W64X", 0);
-        k.plane_chunk = env_int("LITHO_ABBE_PLANE_CHUNK", 0);
-        k.xsplit = env_int("LITHO_ABBE_XSPLIT", 1);
-        k.rect = env_int("LITHO_ABBE_RECT", 1);
-        k.xrect = env_int("LITHO_ABBE_XRECT", 1);
-        k.coarse = env_int("LITHO_ABBE_COARSE", 1);
-        k.gcombine = env_int("LITHO_ABBE_GCOMBINE", 1);
-        k.rowpairs = env_int("LITHO_ABBE_ROWPAIRS", 0);
-        k.poison = env_int("LITHO_ABBE_POISON", 0);
+        LITHO_KNOB(force_generic, "LITHO_ABBE_FORCE_GENERIC", 0);
+        LITHO_KNOB(force_general, "LITHO_ABBE_FORCE_GENERAL", 0);
+        LITHO_KNOB(groups, "LITHO_ABBE_GROUPS", 0);
+        LITHO_KNOB(batch, "LITHO_ABBE_BATCH", 0);
+        LITHO_KNOB(xchunk, "LITHO_ABBE_XCHUNK", 0);
+        LITHO_KNOB(tile, "LITHO_ABBE_TILE", 0);          // 0 = automatic (8 columns on the wave-kernel path, else 4)
+        LITHO_KNOB(w64, "LITHO_ABBE_W64", 1);
+        LITHO_KNOB(w64_8192, "LITHO_ABBE_W64_8192", 1);
+        LITHO_KNOB(w64x, "LITHO_ABBE_W64X", 0);
+        LITHO_KNOB(plane_chunk, "LITHO_ABBE_PLANE_CHUNK", 0);
+        LITHO_KNOB(xsplit, "LITHO_ABBE_XSPLIT", 1);
+        LITHO_KNOB(rect, "LITHO_ABBE_RECT", 1);
+        LITHO_KNOB(xrect, "LITHO_ABBE_XRECT", 1);
+        LITHO_KNOB(coarse, "LITHO_ABBE_COARSE", 1);
+        LITHO_KNOB(gcombine, "LITHO_ABBE_GCOMBINE", 1);
+        LITHO_KNOB(rowpairs, "LITHO_ABBE_ROWPAIRS", 0);
+        LITHO_KNOB(poison, "LITHO_ABBE_POISON", 0);
+#undef LITHO_KNOB
         return k;
     }
 };
@@ -501,6 +513,7 @@ struct AbbePlan {
     bool wave_y;                // y-pass by the wave-level family (k_ypass_wave / k_ypass_pair / k_ypass_rect)
     bool split_x, rect_x, fused_x;   // x-pass: k_xpass_split / k_xpass_rect / plane-fused k_xpass_abbe (else per-plane fall-backs)
     int PC, G, xchunk;          // planes in flight per launch pair, y-pass groups per plane, source points per x-pass workgroup
+    int slabs;                  // slabs per plane the y-pass actually writes: G, or G / 2 when k_ypass_rect<.., 2> folds group pairs
     int64_t bs;                 // source points per batch
 };
 
@@ -559,7 +572,7 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
     const int tile_blocks = !wave_y ? (g.nt + lines_per_wg - 1) / lines_per_wg
                             : wave_wpt == 1 ? (pn + wave_cols - 1) / wave_cols
                                             : wave_wpt * (((pn + tc - 1) / tc + 7) / 8 * 8);
-    const int resident = 256 * (wave_y ? ((N <= 2048 && !rect) ? 4 : 2) : l2n <= 12 ? 3 : (l2n == 13 ? 2 : 1));
+    const int resident = device_cus() * (wave_y ? ((N <= 2048 && !rect) ? 4 : 2) : l2n <= 12 ? 3 : (l2n == 13 ? 2 : 1));
     int a_ = tile_blocks, b_ = resident;
     while (b_) { const int t_ = a_ % b_; a_ = b_; b_ = t_; }
     int Gtot = resident / a_;                                  // groups that fill whole rounds
@@ -657,6 +670,7 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
     pp.general = general; pp.variant = variant; pp.r0 = r0; pp.c0 = c0; pp.h = h; pp.wdt = wdt;
     pp.natural_box = natural_box;
     pp.wave_y = wave_y; pp.PC = PC; pp.G = G; pp.xchunk = xchunk; pp.bs = bs;
+    pp.slabs = (wave_y && rect && g.gcombine && G % 2 == 0) ? G / 2 : G;
     return LITHO_OK;
 }
 
@@ -685,6 +699,17 @@ static hipError_t zero_async(void* p, size_t bytes, hipStream_t st)
     return hipGetLastError();
 }
 
+// Slabs [p * G, p * G + used) of every plane p in flight (the others are never written: k_ypass_rect<.., 2>)
+static hipError_t zero_slabs(float* slab, int pc, int G, int used, size_t slab_plane, hipStream_t st)
+{
+    if (used == G) return zero_async(slab, (size_t)pc * G * slab_plane * sizeof(float), st);
+    for (int p = 0; p < pc; ++p) {
+        const hipError_t e = zero_async(slab + (size_t)p * G * slab_plane, (size_t)used * slab_plane * sizeof(float), st);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 // One chunk of planes (pc <= pp.PC pupils starting at Pc) over the whole source list: slabs zeroed, x-pass / y-pass
 // launch pairs batch by batch, slabs reduced INTO dst[0 .. pc) (each pn x pn, accumulated).
 static int accumulate_chunk(const AbbePlan& pp, const SizeOps* ops, const Workspace& w, const float2* twtab,
@@ -695,7 +720,7 @@ static int accumulate_chunk(const AbbePlan& pp, const SizeOps* ops, const Worksp
     const int variant = pp.variant, G = pp.G, xchunk = pp.xchunk;
     const int64_t bs = pp.bs;
     const size_t slab_plane = (size_t)g.nt * 4 * pn, plane_elems = (size_t)pn * pn;
-    HIP_TRY(zero_async(w.slab, (size_t)pc * G * slab_plane * sizeof(float), st));
+    HIP_TRY(zero_slabs(w.slab, pc, G, pp.slabs, slab_plane, st));
     bool fresh = true;                                     // start a new timing interval after memset / reduce
     int since_flush = 0;
     for (int64_t s0 = 0; s0 < S; s0 += bs) {
@@ -726,7 +751,9 @@ static int accumulate_chunk(const AbbePlan& pp, const SizeOps* ops, const Worksp
         }
         marks.add(0, nb * pc);
         // ---- y-pass: every plane of the chunk, G groups each (fewer when the batch is shorter than G)
-        const int Geff = nb < G ? nb : G;
+        // (a short tail batch, nb < G: as many groups as points -- but never more than the slabs this chunk zeroes and folds)
+        int Geff = nb < G ? nb : G;
+        if (pp.slabs < G && (Geff & 1) && Geff > pp.slabs) Geff = pp.slabs;
         if (pp.wave_y) HIP_TRY(ops->ypass_w64(w.T, w.slab, twtab, g, nb, pc, Geff, G, st));
         else HIP_TRY(ops->ypass_acc(variant, w.T, w.slab, twtab, g, nb, pc, Geff, G, st));
         marks.add(1, nb * pc);
@@ -737,15 +764,15 @@ static int accumulate_chunk(const AbbePlan& pp, const SizeOps* ops, const Worksp
         // scripts/accum_error_probe.py).  Costs one k_slab_reduce + memset per 64 launch pairs (< 0.5 %).
         if (++since_flush == SLAB_FLUSH_BATCHES && s0 + bs < S) {
             hipLaunchKernelGGL(k_slab_reduce, dim3((pn + 31) / 32, (pn + 31) / 32, pc), dim3(256), 0, st,
-                               w.slab, dst, pn, g.nt * 4, G, G);
+                               w.slab, dst, pn, g.nt * 4, pp.slabs, G);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(zero_async(w.slab, (size_t)pc * G * slab_plane * sizeof(float), st));
+            HIP_TRY(zero_slabs(w.slab, pc, G, pp.slabs, slab_plane, st));
             since_flush = 0;
             fresh = true;
         }
     }
     hipLaunchKernelGGL(k_slab_reduce, dim3((pn + 31) / 32, (pn + 31) / 32, pc), dim3(256), 0, st,
-                       w.slab, dst, pn, g.nt * 4, G, G);
+                       w.slab, dst, pn, g.nt * 4, pp.slabs, G);
     HIP_TRY(hipGetLastError());
     return LITHO_OK;
 }
@@ -791,7 +818,8 @@ static int reconstruct_plane(const SizeOps* ops, const SizeOps* ops_c, const Wor
 // planning kernel is launched and the call never waits for the stream; otherwise the plan is made as usual and recorded.
 static int abbe_accumulate(const float2* M, const float2* P, int planes, const int* shifts, int64_t S,
                            const int* count_dev, int64_t* count_out, int pn, int N, float* out, void* ws,
-                           size_t ws_bytes, hipStream_t st, litho_abbe_plan* reuse = nullptr)
+                           size_t ws_bytes, hipStream_t st, litho_abbe_plan* reuse = nullptr,
+                           const litho_abbe_options* opts = nullptr)
 {
     int rc = check_sizes(pn, N);
     if (rc) return rc;
@@ -802,7 +830,8 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     if (!carve(ws, ws_bytes, pn, N, w)) return LITHO_E_WORKSPACE;
     const SizeOps* ops = size_ops(ilog2(N));
     if (!ops) return LITHO_E_ARG;
-    const Knobs kn = Knobs::read();
+    if (opts && (opts->size < (int32_t)sizeof(int32_t) || opts->size > 4096)) return LITHO_E_ARG;
+    const Knobs kn = Knobs::read(opts);
 
     if (kn.poison) {
         // test knob: every scratch region starts the call as NaN bit patterns -- a kernel that reads scratch it (or an
@@ -1021,6 +1050,15 @@ int litho_abbe_accumulate_planned(const void* maskFT, const void* pupil, int pla
     if (!plan) return LITHO_E_ARG;
     return litho::abbe_accumulate((const float2*)maskFT, (const float2*)pupil, planes, shifts, capacity, count_dev,
                                   count_host, pn, N, out, workspace, workspace_bytes, (hipStream_t)stream, plan);
+}
+
+int litho_abbe_accumulate_opts(const void* maskFT, const void* pupil, int planes, const int32_t* shifts,
+                               const int32_t* count_dev, int64_t capacity, int pn, int N, float* out, void* workspace,
+                               size_t workspace_bytes, void* stream, litho_abbe_plan* plan,
+                               const litho_abbe_options* options, int64_t* count_host)
+{
+    return litho::abbe_accumulate((const float2*)maskFT, (const float2*)pupil, planes, shifts, capacity, count_dev,
+                                  count_host, pn, N, out, workspace, workspace_bytes, (hipStream_t)stream, plan, options);
 }
 
 int litho_abbe_field(const void* pf, const void* maskFT, int pn, int N, void* field, void* workspace,

@@ -23,6 +23,18 @@ void note_kernel(int pass, const char* fmt, int a0, int a1, int a2, int a3)
     if (pass < 0 || pass > 1) return;
     g_note[pass] = KernelNote{fmt, {a0, a1, a2, a3}};
 }
+int device_cus()
+{
+    static int cached[64];                       // 0 = not asked yet (benign race: every thread writes the same value)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 256; }
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 256; }
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
 }  // namespace litho
 
 extern "C" {

@@ -9,6 +9,9 @@ void set_last_error(const char* what, hipError_t e);
 // pass 0 (x) / 1 (y): fmt is a string literal with up to four %d, spelt the way rocprofv3 prints the kernel, without
 // "void litho::" and the argument list -- so bench.py and the profiles/ summaries can be matched by name.
 void note_kernel(int pass, const char* fmt, int a0 = 0, int a1 = 0, int a2 = 0, int a3 = 0);
+// Compute units of the CURRENT device (hipDeviceAttributeMultiprocessorCount, cached per device; 256 on an MI355X in
+// SPX mode, 32 per partition in CPX): the launch planners size their grids in whole rounds of it.
+int device_cus();
 }  // namespace litho
 
 #define HIP_TRY(expr)                                   \

@@ -946,7 +946,8 @@ struct SizeImpl {
             hipError_t e = set_lds(once, kern, lds);
             if (e != hipSuccess) return e;
             const int items = ((g.rows + 3) / 4) * nb;
-            const int wgs = items < 512 ? items : 512;               // 256 CUs x 2 resident workgroups
+            const int res = 2 * device_cus();                        // 2 resident workgroups per CU
+            const int wgs = items < res ? items : res;
             const int per = (items + wgs - 1) / wgs;
             hipLaunchKernelGGL(kern, dim3((items + per - 1) / per), dim3(256), lds, st, P, M, shifts, T, tw, g, nb, per);
             note_kernel(0, "k_xpass_w64<%d>", LOG2N);

@@ -50,31 +50,50 @@ class PlanCache:
     optical setting.  Every abbeImage / abbeIntensity call otherwise compacts the source bitmap and reads 56 bytes back
     to plan (pupil support box, shift extents, count): one host wait per image.  With a PlanCache the first call does
     that and records it; later calls with the SAME cache issue no compaction, no planning launch and never wait for the
-    stream, so images queue back to back.  Contract: reuse a cache only while the pupil tensor(s) and the source bitmap
-    are unchanged -- call invalidate() (or make a new one) after changing either; sizes are checked."""
+    stream, so images queue back to back.
+
+    Contract: reuse a cache only while the pupil tensor(s) and the source bitmap are unchanged -- call invalidate() (or
+    make a new one) after changing either.  As a safety net the cache remembers, host-side and without any device
+    access, WHICH tensors it was made for (storage address, shape, torch's in-place version counter, device) and plans
+    afresh when a call arrives with different ones or after an in-place write; a tensor that was freed and whose
+    address and counter happen to come back identical cannot be told apart, hence the contract.
+
+    The cache also HOLDS the engine workspace its calls run in: a HIP graph captured from a planned call carries raw
+    pointers into that workspace, so keep the PlanCache alive for as long as the graph is replayed (the process-wide
+    workspace cache may evict its own reference at any time; this one keeps the memory allocated)."""
 
     def __init__(self):
         self.record = nat.PlanRecord()
         self.shifts = None          # compacted (dy,dx) list of the source bitmap (abbeImage)
         self.count = None           # its device-side count, until the first call has brought it to the host
         self.S = None
+        self.workspace = None       # engine scratch of the planned calls (kept alive for captured graphs)
+        self.identity = None        # what the record was made for (see _identity): abbeIntensity's pupil + shift list
+        self.image_identity = None  # ... and abbeImage's pupil + source bitmap
 
     def invalidate(self):
         self.record.valid = 0
-        self.shifts = self.count = self.S = None
+        self.shifts = self.count = self.S = self.identity = self.image_identity = None
 
     @property
     def valid(self):
         return bool(self.record.valid)
 
 
-def abbeIntensity(maskFT, pupilF, shifts, N, out=None, count=None, plan=None):
+def _identity(*tensors):
+    """Host-only fingerprint of the caller's tensors: (address, shape, in-place version, device) each."""
+    return tuple(None if t is None else (t.data_ptr(), tuple(t.shape), t._version, str(t.device), t.dtype) for t in tensors)
+
+
+def abbeIntensity(maskFT, pupilF, shifts, N, out=None, count=None, plan=None, options=None):
     """The loop of abbeImage (imageformation.py:54-67) for an explicit (dy,dx) list:
     returns / accumulates into the raw fp32 intensity [planes?,pn,pn] BEFORE post-processing.
     pupilF may be [pn,pn] or a through-focus stack [planes,pn,pn].
     `count`: optional 1-element int32 DEVICE tensor holding the number of valid rows of `shifts`
     (sourceShiftsAsync); the call then returns (intensity, S) and the whole image path waits for the
-    stream once.  `plan`: optional PlanCache (see there); the call then returns (intensity, S) as well."""
+    stream once.  `plan`: optional PlanCache (see there); the call then returns (intensity, S) as well.
+    `options`: optional mapping of launch-planner options for THIS call (litho_abbe_options: coarse, batch, groups,
+    xchunk, tile, plane_chunk, ...; see _native.engineOptions), merged over the enclosing engineOptions blocks."""
     pn = _square(maskFT, "maskFT")
     if pupilF.dim() not in (2, 3) or tuple(pupilF.shape[-2:]) != (pn, pn) or (pupilF.dim() == 3 and pupilF.shape[0] < 1):
         # e.g. a default Pupil() (pixelNumber 64) with a 256^2 mask: the reference fails at pf * maskFFFT
@@ -97,10 +116,33 @@ def abbeIntensity(maskFT, pupilF, shifts, N, out=None, count=None, plan=None):
                          f"{out.dtype} {tuple(out.shape)} on {out.device}, contiguous={out.is_contiguous()}")
     rc = nat.lib().litho_abbe_workspace_bytes(pn, int(N), ctypes.byref(ctypes.c_size_t(0)))
     nat.check(rc, "abbeImage")
-    ws = nat.workspace(dev, pn, int(N))
+    if plan is not None:
+        # the planned call's scratch belongs to the PlanCache (graphs captured from it hold raw pointers into it)
+        if (plan.workspace is None or plan.workspace.device != m.device
+                or getattr(plan, "_ws_key", None) != (pn, int(N))):
+            plan.workspace, plan._ws_key = nat.workspace(dev, pn, int(N)), (pn, int(N))
+        ws = plan.workspace
+        ident = _identity(pupilF) + ((shifts.data_ptr(), shifts._version, str(shifts.device)),)   # not the list's length: a
+        # caller may pass the compacted list at its capacity first (with `count`) and as a [:S] view afterwards
+        if plan.valid and plan.identity is not None and plan.identity != ident:
+            plan.record.valid = 0                      # another pupil / source list, or an in-place write: plan afresh
+        plan.identity = ident
+    else:
+        ws = nat.workspace(dev, pn, int(N))
+    opts = nat.current_options(options)
     with torch.cuda.device(dev):
         if count is not None and (count.dtype != torch.int32 or count.numel() != 1 or count.device != m.device):
             raise ShapeError("count must be a 1-element int32 tensor on the mask's device")
+        if opts is not None:
+            S = ctypes.c_int64(0)
+            nat.check(nat.lib().litho_abbe_accumulate_opts(nat.ptr(m), nat.ptr(p), planes, nat.ptr(sh),
+                                                           nat.ptr(count) if count is not None else None, sh.shape[0],
+                                                           pn, int(N), nat.ptr(out), nat.ptr(ws), ws.numel(),
+                                                           nat.stream_ptr(dev),
+                                                           ctypes.byref(plan.record) if plan is not None else None,
+                                                           ctypes.byref(opts), ctypes.byref(S)),
+                      "litho_abbe_accumulate_opts")
+            return (out, S.value) if (plan is not None or count is not None) else out
         if plan is not None:
             S = ctypes.c_int64(0)
             nat.check(nat.lib().litho_abbe_accumulate_planned(nat.ptr(m), nat.ptr(p), planes, nat.ptr(sh),
@@ -204,7 +246,7 @@ def _all_reduce_sum(image, group):
 
 def abbeImage(mask, maskFT: torch.Tensor, pupilF: torch.Tensor, lightsource: torch.Tensor, pixelSize: int,
               deltaK: float, wavelength, fft: bool, device: torch.device, group=None, normalize: bool = False,
-              plan_cache: PlanCache = None):
+              plan_cache: PlanCache = None, options=None):
     """Drop-in for imageformation.py:47-77.  `pupilF` may also be a through-focus stack [planes,pn,pn] (BASELINE
     config 5; the reference's counterpart is a Python loop over Pupil(...) + abbeImage(...)), in which case the
     result is [planes,pn',pn'].
@@ -217,7 +259,9 @@ def abbeImage(mask, maskFT: torch.Tensor, pupilF: torch.Tensor, lightsource: tor
     `normalize`: divide by the number of source points S (the reference returns raw sums, Q7).
 
     `plan_cache`: optional PlanCache for sequences of images with the same pupil and source (single GPU): from the second
-    call on, no source compaction, no planning launches and no host wait."""
+    call on, no source compaction, no planning launches and no host wait.  Not combinable with `group`.
+
+    `options`: optional mapping of launch-planner options for this call (see abbeIntensity)."""
     if not fft:
         raise NotImplementedError("only the FFT formulation (fft=True) is built; the direct integral "
                                   "(imageformation.py:3-30) is outside the hot path")
@@ -234,26 +278,34 @@ def abbeImage(mask, maskFT: torch.Tensor, pupilF: torch.Tensor, lightsource: tor
     maskFT = maskFT.to(dev)
     from .distributed import resolve_group, shard_bounds
     group = resolve_group(group)
-    if group is None and plan_cache is not None:
+    if group is not None and plan_cache is not None:
+        raise ValueError("plan_cache is for single-GPU image sequences; a sharded call (group=...) plans per rank and per "
+                         "call -- pass one or the other")
+    if plan_cache is not None:
         planes = pupilF.shape[0] if pupilF.dim() == 3 else 1
         r = plan_cache.record
-        if plan_cache.shifts is None or not plan_cache.valid or (r.pn, r.N, r.planes) != (pixelNumber, int(N), planes):
+        ident = _identity(pupilF, lightsource)
+        if (plan_cache.shifts is None or not plan_cache.valid or (r.pn, r.N, r.planes) != (pixelNumber, int(N), planes)
+                or plan_cache.image_identity != ident):
             plan_cache.invalidate()
+            plan_cache.image_identity = ident
             plan_cache.shifts, plan_cache.count = sourceShiftsAsync(lightsource.to(dev), pixelNumber)
-            image, total = abbeIntensity(maskFT, pupilF.to(dev), plan_cache.shifts, N, count=plan_cache.count, plan=plan_cache)
+            image, total = abbeIntensity(maskFT, pupilF.to(dev), plan_cache.shifts, N, count=plan_cache.count, plan=plan_cache,
+                                         options=options)
             plan_cache.S, plan_cache.count = total, None           # the count is on the host now (and in the record)
         else:
-            image, total = abbeIntensity(maskFT, pupilF.to(dev), plan_cache.shifts, N, plan=plan_cache)
+            image, total = abbeIntensity(maskFT, pupilF.to(dev), plan_cache.shifts[:plan_cache.S], N, plan=plan_cache,
+                                         options=options)
     elif group is None:
         # single GPU: the source count never visits the host on its own -- one stream wait per image
         shifts, count = sourceShiftsAsync(lightsource.to(dev), pixelNumber)          # imageformation.py:59
-        image, total = abbeIntensity(maskFT, pupilF.to(dev), shifts, N, count=count)  # imageformation.py:62-67
+        image, total = abbeIntensity(maskFT, pupilF.to(dev), shifts, N, count=count, options=options)  # imageformation.py:62-67
     else:
         import torch.distributed as dist
         shifts = sourceShifts(lightsource.to(dev), pixelNumber)            # imageformation.py:59
         total = shifts.shape[0]
         lo, hi = shard_bounds(total, dist.get_rank(group), dist.get_world_size(group))
-        image = abbeIntensity(maskFT, pupilF.to(dev), shifts[lo:hi], N)    # imageformation.py:62-67
+        image = abbeIntensity(maskFT, pupilF.to(dev), shifts[lo:hi], N, options=options)    # imageformation.py:62-67
         _all_reduce_sum(image, group)
     if normalize and total > 0:
         image /= float(total)

@@ -458,6 +458,37 @@ def g12_shard4096():
     save("g12_shard4096.npz", **out)
 
 
+def g13_config3_long_run():
+    """1,536 CONSECUTIVE source points of BASELINE config 3 (2048^2 bernoulli mask, quasar 0.4-0.8, 10-term demo pupil),
+    points [60000, 61536) of the row-major list, by the reference's own abbeImage (raw intensity captured from the same
+    run): 128 launch batches of the engine's default 12-point batch at this size, i.e. MORE than the 64-batch slab fold,
+    so the engine's two-level summation at its default launch geometry is compared with the reference's sequential fp32
+    loop on dense data.  About ten minutes of this container's CPUs."""
+    print("G13 config 3, 1536 consecutive points at 2048^2")
+    import time
+    pn, lo, n = 2048, 60000, 1536
+    out = {}
+    mk = quiet(ref_mask.Mask, bernoulli_mask(pn), PS, CPU)
+    mft = mk.fraunhofer(WL, True)
+    full = source("quasar", pn, 0.4, 0.8)
+    pts = torch.argwhere(full)
+    bm = torch.zeros_like(full)
+    sel = pts[lo:lo + n]
+    bm[sel[:, 0], sel[:, 1]] = 1
+    pf = pupil_fn(pn, DEMO_AB)
+    t0 = time.time()
+    final, raw = full_image_with_raw(mk, mft, pf, bm)
+    out["reference_seconds"] = np.float64(time.time() - t0)
+    for tag, img in (("final", final), ("raw", raw)):
+        crop_stats(f"cfg3run_{tag}", img, out)
+        out[f"cfg3run_{tag}_stride16"] = img[::16, ::16].contiguous()
+    out["cfg3run_range"] = np.array([lo, lo + n, pts.shape[0]], dtype=np.int64)
+    out["cfg3run_first_last_shift"] = shifts_of(bm, pn)[[0, -1]]
+    print(f"   points [{lo},{lo + n}) of {pts.shape[0]}  {float(out['reference_seconds']):.0f} s  final sum "
+          f"{float(final.double().sum()):.7e}", flush=True)
+    save("g13_config3_long_run.npz", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     if os.environ.get("LITHO_GOLDEN_THREADS"):
@@ -466,4 +497,4 @@ if __name__ == "__main__":
     for g in which:
         {"g1": g1_sources, "g2": g2_pupils, "g3": g3_mask_spectra, "g4": g4_fields,
          "g5": g5_images, "g6": g6_through_focus, "g8": g8_large_pupils, "g9": g9_config5_stack, "g10": g10_contiguous_shards,
-         "g11": g11_config2_full, "g12": g12_shard4096}[g]()
+         "g11": g11_config2_full, "g12": g12_shard4096, "g13": g13_config3_long_run}[g]()

@@ -53,6 +53,37 @@ def test_plan_record_layout_matches_the_header(nat):
     assert nat.lib().litho_abbe_accumulate_planned(None, None, 1, None, None, 0, 256, 512, None, None, 0, None, None, None) == nat.E_ARG
 
 
+def test_options_record_layout_matches_the_header(nat):
+    """litho_abbe_options: `size` then int32 fields in the header's order (ctypes mirror: _native.Options); unset = -1."""
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    body = re.search(r"typedef struct litho_abbe_options \{(.*?)\} litho_abbe_options;", text, flags=re.S).group(1)
+    fields = [n.strip() for decl in re.findall(r"int32_t\s+([^;]+);", body) for n in decl.split(",")]
+    assert fields == [f[0] for f in nat.Options._fields_]
+    assert ctypes.sizeof(nat.Options) == 4 * len(fields)
+    o = nat.Options.make({"coarse": 2, "batch": 7})
+    assert o.size == ctypes.sizeof(nat.Options) and o.coarse == 2 and o.batch == 7 and o.tile == -1 and o.poison == -1
+    with pytest.raises(KeyError):
+        nat.Options.make({"no_such_knob": 1})
+    # argument errors before any GPU work: a NULL image, and an options record with an impossible size
+    lib = nat.lib()
+    assert lib.litho_abbe_accumulate_opts(None, None, 1, None, None, 0, 256, 512, None, None, 0, None, None, None, None) == nat.E_ARG
+
+
+def test_engine_options_blocks_nest_and_leave_the_environment_alone(nat):
+    before = dict(os.environ)
+    assert nat.current_options() is None
+    with nat.engineOptions(coarse=2, batch=5):
+        with nat.engineOptions(batch=9):
+            o = nat.current_options({"tile": 8})
+            assert (o.coarse, o.batch, o.tile, o.groups) == (2, 9, 8, -1)
+        o = nat.current_options()
+        assert (o.coarse, o.batch, o.tile) == (2, 5, -1)
+    assert nat.current_options() is None and dict(os.environ) == before
+    with pytest.raises(KeyError):
+        with nat.engineOptions(bogus=1):
+            pass
+
+
 def test_target_arch_and_version(nat):
     assert nat.lib().litho_target_arch() == b"gfx950"
     assert nat.lib().litho_version() >= 100

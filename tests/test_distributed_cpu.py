@@ -87,7 +87,7 @@ def _product_worker(rank, world, port, out_path):
         nat.require_gpu = lambda d: d if isinstance(d, torch.device) else torch.device(d)
         IF.sourceShifts = lambda bm, pn: O.source_shifts(bm, pn)
 
-        def fake_intensity(mft, pf, shifts, N, out=None):
+        def fake_intensity(mft, pf, shifts, N, out=None, options=None):
             calls.append(int(shifts.shape[0]))
             if pf.dim() == 3:
                 return torch.stack([O.abbe_raw(mft, p, shifts, N) if shifts.shape[0] else torch.zeros(mft.shape) for p in pf])

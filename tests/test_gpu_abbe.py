@@ -477,18 +477,22 @@ def test_contiguous_shard_vs_golden(golden, L, dev, monkeypatch, tag, pn, skind,
     assert abs(float(raw.double().sum()) / float(g[f"{tag}_raw_sum"]) - 1) < 2e-6
 
 
-@pytest.mark.parametrize("path", ["coarse", "direct", "coarse-tile8", "coarse-tile8-rowpairs"])
+@pytest.mark.parametrize("path", ["coarse", "direct", "coarse-tile8", "coarse-tile8-rowpairs", "coarse-default-batch", "direct-default-batch"])
 def test_consecutive_shard_4096_vs_golden(golden, L, dev, monkeypatch, path):
     """BASELINE config 4's size: 64 CONSECUTIVE source points [800000, 800064) of the 4096^2 annular list, run by the
     reference's own abbeImage (golden g12): several launch batches of the 4096-point kernels, raw intensity and the
     4094^2 post-processed image (quirk Q5), default (coarse-grid: 16-column T tiles, k_ypass_coop) and direct evaluation,
-    and the coarse grid on 8-column tiles (k_ypass_wave<12, 8, true>; with and without the row-pair x-pass)."""
+    and the coarse grid on 8-column tiles (k_ypass_wave<12, 8, true>; with and without the row-pair x-pass).  The
+    "-default-batch" runs leave the launch geometry to the planner, as a caller gets it: ONE 60-item batch with 15-point
+    x-pass chunks plus a ragged batch of 4 (asserted) -- config 4's production geometry on the reference's dense data."""
     from lithographysimulator_amd import _native as nat
     from lithographysimulator_amd.synthetic import bernoulli_mask
     g = golden("g12_shard4096.npz")
     pn = 4096
     monkeypatch.setenv("LITHO_ABBE_COARSE", "2" if path.startswith("coarse") else "0")
-    monkeypatch.setenv("LITHO_ABBE_BATCH", "12")               # 64 points = 5 full batches + a ragged one (the default batch is 60 here)
+    default_batch = path.endswith("default-batch")
+    if not default_batch:
+        monkeypatch.setenv("LITHO_ABBE_BATCH", "12")           # 64 points = 5 full batches + a ragged one (the default batch is 60 here)
     if "tile8" in path: monkeypatch.setenv("LITHO_ABBE_TILE", "8")
     if "rowpairs" in path: monkeypatch.setenv("LITHO_ABBE_ROWPAIRS", "1")
     lo, hi, S = (int(v) for v in g["cfg4shard_range"])
@@ -502,10 +506,12 @@ def test_consecutive_shard_4096_vs_golden(golden, L, dev, monkeypatch, path):
     pf = L.Pupil(pn, WL, NA, f16([0, 0, 0, 0, 100]), dev).generatePupilFunction()
     raw = L.abbeIntensity(mft, pf, sel, N)
     plan = nat.last_plan()
-    assert plan["coarse_grid"] == (1 if path.startswith("coarse") else 0) and plan["launches"] >= 4, plan
+    assert plan["coarse_grid"] == (1 if path.startswith("coarse") else 0) and plan["launches"] >= (2 if default_batch else 4), plan
+    if default_batch:
+        assert (plan["batch"], plan["launches"], plan["xchunk"]) == (60, 2, 15), plan
     kx, ky = nat.last_kernels()
     if path.startswith("coarse"):
-        assert ky == ("k_ypass_coop<12, 4>" if path == "coarse" else "k_ypass_wave<12, 8, true>"), (kx, ky)
+        assert ky == ("k_ypass_coop<12, 4>" if path in ("coarse", "coarse-default-batch") else "k_ypass_wave<12, 8, true>"), (kx, ky)
         assert kx == ("k_xpass_abbe<12, 0, true, 1, 2>" if "rowpairs" in path else "k_xpass_abbe<12, 0, true, 1, 1>"), (kx, ky)
     final = L.postProcess(raw, eps).cpu()
     raw = raw.cpu()

@@ -1,0 +1,341 @@
+"""Boundary and randomized differential tests of the launch PLANNER (csrc/abbe_engine.hip: plan_abbe + the coarse-grid
+gates of abbe_accumulate) against the CPU oracle, through the C ABI.
+
+The reference accepts ANY pupil function and ANY shift (imageformation.py:32-45, 62-67): whichever kernel family the
+planner picks -- natural-box wave kernels, radix-16 fall-backs, the coarse grid, general (wrapping) mode -- the image must
+be the reference's.  The gates that decide are fed here from both sides of every threshold, with the decision asserted
+through litho_abbe_last_plan, and a seeded fuzz walks the rest (random supports, shifts, stacks and planner options,
+scratch poisoned with NaN, `out` pre-filled).  Options travel through litho_abbe_options (no os.environ)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import NA, PS, TOL_IMAGE_L2, TOL_IMAGE_MAX, WL, f16, rel_l2, rel_max
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def L():
+    import lithographysimulator_amd as L
+    from lithographysimulator_amd import _native as nat
+    assert nat.lib().litho_target_arch() == b"gfx950"
+    return L
+
+
+def O():
+    from oracle import abbe_oracle
+    return abbe_oracle
+
+
+def nat():
+    from lithographysimulator_amd import _native
+    return _native
+
+
+def _mask_spectrum(L, dev, pn):
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    return L.Mask(bernoulli_mask(pn), PS, dev).fraunhofer(WL, True)
+
+
+def _disk(L, dev, pn, defocus=60):
+    return L.Pupil(pn, WL, NA, f16([0, 0, 0, 0, defocus]), dev).generatePupilFunction().clone()
+
+
+def _rand_c64(gen, *shape):
+    return torch.polar(0.5 + 0.5 * torch.rand(*shape, generator=gen), 6.2831853 * torch.rand(*shape, generator=gen)).to(torch.complex64)
+
+
+def _strided_points(L, dev, pn, K, sin=0.4, sout=0.8):
+    sh = L.sourceShifts(L.LightSource(sin, sout, pn, NA, device=dev).generateAnnular(), pn)
+    return sh[(torch.arange(K, device=dev) * sh.shape[0]) // K].contiguous()
+
+
+def _check(got, ref, what):
+    e, l2 = rel_max(got, ref), rel_l2(got, ref)
+    print(f"{what}: rel-to-max {e:.2e}, rel-L2 {l2:.2e}")
+    assert e < TOL_IMAGE_MAX and l2 < TOL_IMAGE_L2, what
+
+
+# ------------------------------------------------------------------ coarse-grid refusal: box corners
+@pytest.mark.parametrize("pn,K", [(512, 8), (1024, 6), (2048, 3)])
+def test_square_pupil_with_set_corners_leaves_the_coarse_grid(L, dev, pn, K):
+    """A square aperture filling |k| <= pn/4 has the natural box but SET CORNERS: the Nyquist-line correction of the
+    coarse grid (products of opposite box edges only) does not cover the corner coefficient, so the planner must stay
+    on the direct path -- asked politely (coarse = 1) or firmly (2) -- and the wave kernels must take a full box."""
+    o = O()
+    N, c, h = 2 * pn, pn // 2, pn // 4
+    gen = torch.Generator().manual_seed(pn)
+    pupil = torch.zeros(pn, pn, dtype=torch.complex64)
+    pupil[c - h:c + h + 1, c - h:c + h + 1] = _rand_c64(gen, 2 * h + 1, 2 * h + 1)
+    mft = _mask_spectrum(L, dev, pn)
+    sel = _strided_points(L, dev, pn, K)
+    ref = o.abbe_raw(mft.cpu(), pupil, sel.cpu(), N)
+    for coarse in (1, 2):
+        got = L.abbeIntensity(mft, pupil.to(dev), sel, N, options={"coarse": coarse}).cpu()
+        plan = nat().last_plan()
+        assert plan["coarse_grid"] == 0 and plan["natural_box"] == 1 and plan["general"] == 0, plan
+        assert (plan["box_rows"], plan["box_cols"]) == (2 * h + 1, 2 * h + 1), plan
+        _check(got, ref, f"{pn}^2 square pupil, coarse={coarse}, y-pass {nat().last_kernels()[1]}")
+    # one corner alone is enough to refuse; none, and the same call runs on the coarse grid
+    for corner, expect in (((c + h, c - h), 0), (None, 1)):
+        p2 = _disk(L, dev, pn)
+        if corner:
+            p2[corner] = 0.7 - 0.2j
+        got = L.abbeIntensity(mft, p2, sel, N, options={"coarse": 2}).cpu()
+        assert nat().last_plan()["coarse_grid"] == expect, (corner, nat().last_plan())
+        _check(got, o.abbe_raw(mft.cpu(), p2.cpu(), sel.cpu(), N), f"{pn}^2 disk, corner {corner}")
+
+
+# ------------------------------------------------------------------ coarse-grid refusal: box-edge support 128 / 129
+@pytest.mark.parametrize("pn,K", [(1024, 6), (2048, 3)])
+@pytest.mark.parametrize("edge", ["columns", "rows"])
+@pytest.mark.parametrize("length", [128, 129])
+def test_box_edge_support_at_the_coarse_grid_limit(L, dev, pn, K, edge, length):
+    """Disk + a rim on the two opposite edges of the natural box whose joint support is exactly 128 samples (the most
+    k_nyquist_edges handles: coarse grid, with 255 non-zero Nyquist-line coefficients) or 129 (must leave it)."""
+    o = O()
+    N, c, h = 2 * pn, pn // 2, pn // 4
+    gen = torch.Generator().manual_seed(1000 * pn + length)
+    pupil = _disk(L, dev, pn).cpu()
+    lo = c - 64
+    a = _rand_c64(gen, length)              # edge +h: the whole support
+    b = _rand_c64(gen, 51)                  # edge -h: an inner part of it
+    if edge == "columns":
+        pupil[lo:lo + length, c + h] = a
+        pupil[c - 30:c + 21, c - h] = b
+    else:
+        pupil[c + h, lo:lo + length] = a
+        pupil[c - h, c - 30:c + 21] = b
+    mft = _mask_spectrum(L, dev, pn)
+    sel = _strided_points(L, dev, pn, K)
+    ref = o.abbe_raw(mft.cpu(), pupil, sel.cpu(), N)
+    for coarse in (2, 0):
+        got = L.abbeIntensity(mft, pupil.to(dev), sel, N, options={"coarse": coarse}).cpu()
+        plan = nat().last_plan()
+        assert plan["natural_box"] == 1 and plan["general"] == 0, plan
+        assert plan["coarse_grid"] == (1 if coarse == 2 and length <= 128 else 0), (length, coarse, plan)
+        _check(got, ref, f"{pn}^2 rim on {edge}, support {length}, coarse={coarse} -> coarse_grid {plan['coarse_grid']}")
+
+
+def test_stack_in_which_one_plane_alone_violates(L, dev):
+    """The plan words are taken over ALL planes of a stack: if plane 1 alone has a 129-sample edge (or a set corner), the
+    whole stack leaves the coarse grid; with a 128-sample edge on plane 1 only it stays, and the edge sums of planes 0
+    and 2 (one sample per edge) use the joint support."""
+    o = O()
+    pn, K = 1024, 4
+    N, c, h = 2 * pn, pn // 2, pn // 4
+    gen = torch.Generator().manual_seed(77)
+    mft = _mask_spectrum(L, dev, pn)
+    sel = _strided_points(L, dev, pn, K)
+    for what, expect in (("edge128", 1), ("edge129", 0), ("corner", 0)):
+        stack = torch.stack([_disk(L, dev, pn, d).cpu() for d in (-80, 20, 120)])
+        if what == "corner":
+            stack[1, c - h, c - h] = 0.3 + 0.4j
+        else:
+            n = 128 if what == "edge128" else 129
+            stack[1, c - 64:c - 64 + n, c - h] = _rand_c64(gen, n)
+            stack[1, c - 10:c + 10, c + h] = _rand_c64(gen, 20)
+        for pc in (1, 2):
+            got = L.abbeIntensity(mft, stack.to(dev), sel, N, options={"coarse": 2, "plane_chunk": pc}).cpu()
+            plan = nat().last_plan()
+            assert plan["coarse_grid"] == expect and plan["natural_box"] == 1, (what, plan)
+            for k in range(3):
+                _check(got[k], o.abbe_raw(mft.cpu(), stack[k], sel.cpu(), N), f"stack {what}, plane chunk {pc}, plane {k}")
+
+
+# ------------------------------------------------------------------ natural box: pn/4 and pn/4 + 1 on each side
+@pytest.mark.parametrize("pn", [512, 1024])
+@pytest.mark.parametrize("side", ["col_hi", "col_lo", "row_hi", "row_lo"])
+def test_support_box_one_sample_inside_and_outside_the_natural_box(L, dev, pn, side):
+    """One extra pupil sample AT |k| = pn/4 (still the natural box: wave kernels, coarse grid) and at pn/4 + 1 (the box
+    check must send the call to the radix-16 kernels on the direct path) on each of the four sides."""
+    o = O()
+    N, c, h = 2 * pn, pn // 2, pn // 4
+    mft = _mask_spectrum(L, dev, pn)
+    sel = _strided_points(L, dev, pn, 6)
+    for beyond in (0, 1):
+        pupil = _disk(L, dev, pn).cpu()
+        k = h + beyond
+        pos = {"col_hi": (c + 5, c + k), "col_lo": (c - 7, c - k), "row_hi": (c + k, c + 9), "row_lo": (c - k, c - 3)}[side]
+        pupil[pos] = -0.6 + 0.5j
+        ref = o.abbe_raw(mft.cpu(), pupil, sel.cpu(), N)
+        for coarse in (2, 0):
+            got = L.abbeIntensity(mft, pupil.to(dev), sel, N, options={"coarse": coarse}).cpu()
+            plan = nat().last_plan()
+            assert plan["natural_box"] == 1 - beyond and plan["general"] == 0, (side, beyond, plan)
+            assert plan["coarse_grid"] == (1 if coarse == 2 and not beyond else 0), (side, beyond, plan)
+            assert plan["wave_ypass"] == 1 - beyond, (side, beyond, plan)
+            assert max(plan["box_rows"], plan["box_cols"]) == 2 * h + 1 + beyond, plan
+            _check(got, ref, f"{pn}^2 extra sample {side} at pn/4+{beyond}, coarse={coarse}, kernels {nat().last_kernels()}")
+
+
+# ------------------------------------------------------------------ source-count threshold of the default mode
+@pytest.mark.parametrize("pn,s_min", [(512, 1536), (1024, 384)])
+def test_source_count_threshold_of_the_coarse_grid(L, dev, pn, s_min):
+    """Default mode (coarse = 1): S = s_min - 1 stays on the direct path, S = s_min takes the coarse grid; both are the
+    reference's image (the oracle's sequential fp32 loop over the same consecutive points)."""
+    o = O()
+    N = 2 * pn
+    mft = _mask_spectrum(L, dev, pn)
+    pupil = _disk(L, dev, pn, 100)
+    sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateAnnular(), pn)
+    lo = sh.shape[0] // 3
+    sel = sh[lo:lo + s_min].contiguous()
+    ref_short = o.abbe_raw(mft.cpu(), pupil.cpu(), sel[:-1].cpu(), N)
+    ref_full = ref_short + o.abbe_raw(mft.cpu(), pupil.cpu(), sel[-1:].cpu(), N)
+    for S, ref, expect in ((s_min - 1, ref_short, 0), (s_min, ref_full, 1)):
+        got = L.abbeIntensity(mft, pupil, sel[:S].contiguous(), N, options={"coarse": 1}).cpu()
+        plan = nat().last_plan()
+        assert plan["coarse_grid"] == expect and plan["natural_box"] == 1, (S, plan)
+        _check(got, ref, f"{pn}^2 S = {S} (threshold {s_min}) -> coarse_grid {expect}")
+
+
+# ------------------------------------------------------------------ wrapping: one sample short of it and one past
+@pytest.mark.parametrize("pn", [256, 512])
+@pytest.mark.parametrize("axis,sign", [(0, -1), (0, 1), (1, -1), (1, 1)])
+def test_shift_one_sample_short_of_wrapping_and_one_past(L, dev, pn, axis, sign):
+    """The disk's box is rows/columns [c - h, c + h]: a shift of -(c - h) puts its first row on row 0 (no wrap: pruned
+    box mode, coarse grid allowed, mask samples read at the very edge of the grid), one more wraps (general mode: roll
+    kept on P, modular gather).  Same on the high side (last row on row pn - 1) and along x."""
+    o = O()
+    N, c, h = 2 * pn, pn // 2, pn // 4
+    mft = _mask_spectrum(L, dev, pn)
+    pupil = _disk(L, dev, pn)
+    edge = -(c - h) if sign < 0 else (pn - 1) - (c + h)           # the last shift that does not wrap
+    for past in (0, 1):
+        big = edge + sign * past
+        pts = [[3, -5], [0, 0], [-11, 17]]
+        pts[1][axis] = big
+        pts.append([big if axis == 0 else 2, big if axis == 1 else -4])
+        sel = torch.tensor(pts, dtype=torch.int32, device=dev)
+        ref = o.abbe_raw(mft.cpu(), pupil.cpu(), sel.cpu(), N)
+        for coarse in (2, 0):
+            got = L.abbeIntensity(mft, pupil, sel, N, options={"coarse": coarse}).cpu()
+            plan = nat().last_plan()
+            assert plan["general"] == past, (axis, sign, past, plan)
+            assert plan["coarse_grid"] == (1 if coarse == 2 and not past else 0), (axis, sign, past, plan)
+            _check(got, ref, f"{pn}^2 shift {big} on axis {axis} (wraps: {past}), coarse={coarse}")
+
+
+# ------------------------------------------------------------------ seeded fuzz
+FUZZ_CASES = 240
+
+
+def _fuzz_pupil(gen, kind, pn):
+    c, h = pn // 2, pn // 4
+    p = torch.zeros(pn, pn, dtype=torch.complex64)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=gen))          # noqa: E731  inclusive
+    if kind == "empty":
+        return p
+    if kind == "single":
+        p[ri(0, pn - 1), ri(0, pn - 1)] = complex(_rand_c64(gen, 1)[0])
+        return p
+    if kind == "full":
+        return _rand_c64(gen, pn, pn)
+    if kind == "box":                                                             # any rectangle, random fill density
+        r0, r1 = sorted((ri(0, pn - 1), ri(0, pn - 1)))
+        c0, c1 = sorted((ri(0, pn - 1), ri(0, pn - 1)))
+        blk = _rand_c64(gen, r1 - r0 + 1, c1 - c0 + 1)
+        if ri(0, 1):
+            blk = blk * (torch.rand(blk.shape, generator=gen) < 0.3)
+        p[r0:r1 + 1, c0:c1 + 1] = blk
+        return p
+    # disk family: the reference's r <= 1 support (|k| <= pn/4), optionally with samples around the natural box's edges
+    yy, xx = torch.meshgrid(torch.arange(pn) - c, torch.arange(pn) - c, indexing="ij")
+    inside = (yy * yy + xx * xx) <= h * h
+    p = torch.where(inside, _rand_c64(gen, pn, pn), p)
+    if kind == "disk_rim":                                                        # stays inside |k| <= pn/4
+        n = ri(1, min(2 * h + 1, 140))
+        a = ri(c - h, c + h - n + 1) if 2 * h + 1 >= n else c - h
+        if ri(0, 1):
+            p[a:a + n, c + (h if ri(0, 1) else -h)] = _rand_c64(gen, n)
+        else:
+            p[c + (h if ri(0, 1) else -h), a:a + n] = _rand_c64(gen, n)
+        if ri(0, 3) == 0:
+            p[c + (h if ri(0, 1) else -h), c + (h if ri(0, 1) else -h)] = 1j     # a corner
+    if kind == "disk_junk":                                                       # a few samples within +-2 of the box edges
+        for _ in range(ri(1, 4)):
+            k = h + ri(-2, 2)
+            t = ri(-h, h)
+            pos = [(c + t, c + k), (c + t, c - k), (c + k, c + t), (c - k, c + t)][ri(0, 3)]
+            if 0 <= pos[0] < pn and 0 <= pos[1] < pn:
+                p[pos] = complex(_rand_c64(gen, 1)[0])
+    return p
+
+
+def _fuzz_case(seed):
+    gen = torch.Generator().manual_seed(900000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=gen))          # noqa: E731
+    pick = lambda seq: seq[ri(0, len(seq) - 1)]                                      # noqa: E731
+    pn = pick([64, 96, 128, 256, 256, 512])
+    ps = pick([25, 25, 10, 48])
+    kind = pick(["disk", "disk", "disk_rim", "disk_junk", "box", "box", "single", "full", "empty"])
+    planes = pick([1, 1, 1, 2, 3, 5])
+    budget = {64: 40, 96: 30, 128: 24, 256: 12, 512: 5}[pn]                          # source points x planes the oracle gets
+    S = max(1, min(ri(1, 14), budget // planes))
+    c, h = pn // 2, pn // 4
+    mode = pick(["narrow", "narrow", "wide", "wrap"])
+    lim = {"narrow": max(1, int(0.2 * pn)), "wide": c - h, "wrap": c}[mode]
+    sh = torch.randint(-lim, lim + (0 if mode == "wrap" else 1), (S, 2), generator=gen, dtype=torch.int32)
+    if S > 2 and ri(0, 1):
+        sh[ri(0, S - 1)] = sh[0]                                                     # duplicates are legal source lists
+    opts = {"poison": 1, "coarse": pick([0, 1, 2, 2])}
+    for name, values in (("batch", [0, 0, 1, 2, 3, 5, 8]), ("groups", [0, 0, 1, 2, 3, 4]), ("xchunk", [0, 0, 1, 2, 3]),
+                         ("tile", [0, 0, 4, 8]), ("plane_chunk", [0, 1, 2, 4]), ("gcombine", [1, 1, 0]),
+                         ("rect", [1, 1, 0]), ("w64", [1, 1, 1, 0]), ("xrect", [1, 1, 0, 2]), ("force_generic", [0, 0, 0, 1]),
+                         ("force_general", [0, 0, 0, 0, 1])):
+        opts[name] = pick(values)
+    pupils = torch.stack([_fuzz_pupil(gen, kind, pn) for _ in range(planes)])
+    mft = torch.complex(torch.randn(pn, pn, generator=gen), torch.randn(pn, pn, generator=gen))
+    prefill = torch.rand(planes, pn, pn, generator=gen) if ri(0, 1) else torch.zeros(planes, pn, pn)
+    return dict(seed=seed, pn=pn, ps=ps, kind=kind, planes=planes, shifts=sh, opts=opts, pupils=pupils, mft=mft,
+                prefill=prefill, mode=mode)
+
+
+def test_seeded_fuzz_against_the_float64_oracle(L, dev):
+    o = O()
+    failures, worst, paths = [], 0.0, {}
+    for seed in range(FUZZ_CASES):
+        cs = _fuzz_case(seed)
+        pn = cs["pn"]
+        _, N = L.Mask.calculateEpsilonN(None, 4 / pn, cs["ps"], WL)
+        ref = torch.stack([o.abbe_raw_f64(cs["mft"], cs["pupils"][k], cs["shifts"], N) for k in range(cs["planes"])])
+        scale = float(ref.max()) if float(ref.max()) > 0 else 1.0
+        pre = (cs["prefill"].double() * 0.25 * scale).float()
+        want = pre.double() + ref
+        stacked = cs["planes"] > 1
+        out = (pre if stacked else pre[0]).clone().to(dev)
+        pup = (cs["pupils"] if stacked else cs["pupils"][0]).to(dev)
+        tag = f"seed {seed}: pn {pn} N {N} {cs['kind']} planes {cs['planes']} S {cs['shifts'].shape[0]} {cs['mode']} {cs['opts']}"
+        try:
+            got = L.abbeIntensity(cs["mft"].to(dev), pup, cs["shifts"].to(dev), N, out=out, options=cs["opts"]).cpu().double()
+        except Exception as exc:                                                     # noqa: BLE001  report every seed
+            failures.append(f"{tag}: raised {type(exc).__name__}: {exc}")
+            continue
+        got = got if stacked else got[None]
+        plan = nat().last_plan()
+        key = ("general" if plan["general"] else "coarse" if plan["coarse_grid"] else "direct",
+               "wave" if plan["wave_ypass"] else "r16", plan["variant"])
+        if cs["kind"] != "empty":
+            paths[key] = paths.get(key, 0) + 1
+        if not torch.isfinite(got).all():
+            failures.append(f"{tag}: non-finite pixels (poisoned scratch read?) plan {plan}")
+            continue
+        e = float((got - want).abs().max() / scale)
+        l2 = float(torch.linalg.norm(got - want) / max(float(torch.linalg.norm(want)), 1e-300))
+        worst = max(worst, e)
+        if e >= TOL_IMAGE_MAX or l2 >= TOL_IMAGE_L2:
+            failures.append(f"{tag}: rel-to-max {e:.2e} rel-L2 {l2:.2e} plan {plan} kernels {nat().last_kernels()}")
+    print(f"fuzz: {FUZZ_CASES} cases, worst rel-to-max {worst:.2e}; evaluation paths hit: "
+          + ", ".join(f"{k}: {v}" for k, v in sorted(paths.items(), key=str)))
+    assert not failures, "\n".join(failures[:40])
+    # the fuzz is only worth its name if it reaches every family of the planner
+    fams = {k[0] for k in paths}
+    assert {"general", "coarse", "direct"} <= fams and any(k[1] == "wave" for k in paths) and any(k[1] == "r16" for k in paths), paths

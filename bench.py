@@ -195,7 +195,53 @@ def measured_ceilings(torch, dev):
         return None, None
 
 
-def extra_workload(torch, nat, dev, name, shard=None, steps=1, warm_points=0, profile_points=480):
+CPU_SAMPLE_POINTS = {256: 64, 1024: 16, 2048: 8, 4096: 4}      # BASELINE.md / SURVEY 8d: K source points per grid size
+
+
+def cpu_baseline(torch, nat, w, plan, full=False, reps=3):
+    """The reference's CPU path beside the GPU number, in the same run on the GPU box's own host cores: the oracle's
+    torch-CPU op chain (oracle/abbe_oracle.py abbe_raw: roll / mul / pad / fftshift / ifft2 / ifftshift / crop / abs^2 / add,
+    a port of imageformation.py:62-67; the reference's Python itself does not travel to the GPU box) over K source points
+    strided through the real list -- the loop is strictly linear in S -- or, `full`, over the WHOLE list once (config 1, as
+    BASELINE.md asks).  The same points then go through the GPU on the evaluation path the timed step ran (options, not
+    the environment) for a parity figure.  Reported, not optimised."""
+    import lithographysimulator_amd as L
+    from oracle import abbe_oracle as O
+    pn, N, planes, S_full, dev = w.pn, w.N, w.planes, w.S_full, w.dev
+    # 32 threads is the fastest setting for this op chain on the GPU box's 2 x EPYC 9575F (256 hw threads:
+    # 8 -> 2.1e7, 32 -> 2.6e7, 256 -> 1.6e6 pt*px/s; scripts/cpu_threads_probe.py), so that is the baseline.
+    host_cpus = os.cpu_count() or 1
+    torch.set_num_threads(min(host_cpus, 32))
+    shifts = L.sourceShifts(w.bitmap, pn)
+    K = S_full if full else CPU_SAMPLE_POINTS.get(pn, 8)
+    sel = shifts.cpu() if full else shifts[(torch.arange(K, device=dev) * S_full) // K].cpu()
+    p_one = w.pupil if planes == 1 else w.pupil[planes // 2]
+    m_cpu, p_cpu = w.maskFT.cpu(), p_one.cpu()
+    O.abbe_raw(m_cpu, p_cpu, sel[:1], N)                        # warm-up
+    times = []
+    for _ in range(1 if full else reps):
+        c0 = time.perf_counter()
+        ref_raw = O.abbe_raw(m_cpu, p_cpu, sel, N)
+        times.append(time.perf_counter() - c0)
+    tmed = statistics.median(times)
+    # the parity sample runs the evaluation path of the TIMED step (a handful of points would otherwise fall below
+    # the coarse-grid path's source-count threshold and check the direct kernels instead)
+    gpu_raw = L.abbeIntensity(w.maskFT, p_one, sel.to(dev), N, options={"coarse": 2 if plan.get("coarse_grid") else 0}).cpu()
+    parity_plan = nat.last_plan()
+    assert parity_plan["coarse_grid"] == plan.get("coarse_grid"), (parity_plan, plan)
+    parity = float((gpu_raw - ref_raw).abs().max() / ref_raw.max())
+    how = (f"ALL {K} source points of the list, once, {tmed:.2f} s" if full else
+           f"{K} source points strided through the {S_full}-point list, 1 warm-up + {reps} reps, median {tmed:.2f} s")
+    return {"value": K * pn * pn / tmed, "unit": "source-pt*px/s", "cores": torch.get_num_threads(), "host_cpus": host_cpus,
+            "kind": "port",
+            "sample": how + f", full {pn}x{pn} grid" + (f", plane {planes // 2} of {planes}" if planes > 1 else "") +
+                      "; oracle/abbe_oracle.py abbe_raw (torch-CPU roll/mul/pad/fftshift/ifft2/ifftshift/crop/abs2/add)",
+            "seconds": tmed, "source_points": K,
+            "gpu_vs_cpu_rel_to_max": parity,
+            "parity_path": {"coarse_grid": parity_plan["coarse_grid"], "kernels": list(nat.last_kernels())}}
+
+
+def extra_workload(torch, nat, dev, name, shard=None, steps=1, warm_points=0, profile_points=480, cpu=True):
     """One or two timed steps of another BASELINE configuration (same fences as the headline), plus a short profiled
     run for the x-pass / y-pass split."""
     import lithographysimulator_amd as L
@@ -250,6 +296,11 @@ def extra_workload(torch, nat, dev, name, shard=None, steps=1, warm_points=0, pr
         torch.cuda.synchronize()
         t_seq = (time.perf_counter() - t0) / 100
         out["sequence_with_plan_cache"] = {"images": 100, "ms_per_image": t_seq * 1e3, "value": units / t_seq}
+    if cpu:
+        try:
+            out["cpu_baseline"] = cpu_baseline(torch, nat, w, plan, full=(name == "cfg1"))
+        except Exception as exc:
+            out["cpu_baseline"] = {"error": repr(exc)}
     del w, image
     torch.cuda.empty_cache()
     return out
@@ -378,8 +429,16 @@ def main():
         try:
             entry = json.load(open(tpath)).get(args.workload, {})
             traffic_src = entry.get("source")
+            if entry.get("commit"):
+                traffic_src = f"{traffic_src} [captured at commit {entry['commit']}]"
             for k in kern:
                 per_item = entry.get(k + "_bytes_per_item")
+                # counters are only meaningful for the kernel they were collected on: an entry made for another kernel
+                # (a renamed / re-parametrised variant since the capture) is dropped, not reused
+                made_for = entry.get(k + "_kernel")
+                if made_for is not None and made_for != kern[k]["kernel"]:
+                    kern[k]["traffic_stale"] = f"profiles/traffic.json holds counters of {made_for}, this run launched {kern[k]['kernel']}"
+                    continue
                 if per_item is not None and kern[k]["avg_launch_ms"] > 0:
                     kern[k]["traffic"] = per_item * kern[k]["items_per_launch"]
                     kern[k]["fabric_GBs"] = kern[k]["traffic"] / (kern[k]["avg_launch_ms"] * 1e-3) / 1e9
@@ -399,8 +458,9 @@ def main():
     fabric_gbs = traffic / dom_s / 1e9 if traffic and dom_s > 0 else None
     # "bound" takes the contract's two values ("hbm" | "mfma"): this is the flop side -- priced against the dense fp32 peak,
     # 157.3 TFLOP/s, which on gfx950 is the same figure for the matrix and the vector pipe; `bound_detail` says which pipe
-    roofline = {"bound": "mfma", "bound_detail": "fp32 vector (VALU) issue: the path has no MFMA work; dense fp32 peak of the vector pipe = of "
-                                                  "the matrix pipe = 157.3 TFLOP/s", "kernel": kern[dom]["kernel"],
+    roofline = {"bound": "mfma", "bound_detail": "VALU: fp32 vector issue, NOT the matrix pipe -- the path has no MFMA instruction; \"mfma\" is the "
+                                                  "contract's name for the flop side, priced at the dense fp32 peak, which on gfx950 is "
+                                                  "157.3 TFLOP/s for the vector and the matrix pipe alike", "kernel": kern[dom]["kernel"],
                 "achieved": kern[dom]["achieved_TFLOPs"], "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": kern[dom]["achieved_TFLOPs"] / VALU_PEAK_TFLOPS, "traffic": traffic,
                 "avg_launch_ms": kern[dom]["avg_launch_ms"],
@@ -418,7 +478,10 @@ def main():
                         "L2 exchanged with the fabric per launch of this workload, Infinity-Cache hits INCLUDED (T is kept "
                         "inside that cache on purpose): an upper bound on HBM traffic, not HBM traffic.  effective_40B_* "
                         "divide the SURVEY 8d byte MODEL by x-pass + y-pass kernel time: most of those bytes are never "
-                        "moved, so it exceeds the peak and is not a roofline fraction",
+                        "moved, so it exceeds the peak and is not a roofline fraction.  avg_launch_ms comes from HIP events the "
+                        "library records around every launch of ONE extra, untimed step: the marks themselves cost about 4 % "
+                        "(launches x avg_launch_ms of both kernels exceeds ms_per_step by that much), so achieved / frac are "
+                        "slightly conservative; rocprofv3 --kernel-trace of the same command (profiles/) has the unmarked durations",
                 "traffic_source": traffic_src,
                 "pipeline": {"achieved": both_flops / (both_ms * 1e-3) / 1e12 if both_ms else 0.0,
                              "frac": both_flops / (both_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS if both_ms else 0.0,
@@ -440,44 +503,7 @@ def main():
 
     # ---- CPU baseline leg: the oracle's op-chain port of the reference loop, rank 0, N = 1 only
     if world == 1 and not args.no_cpu_baseline:
-        from oracle import abbe_oracle as O
-        # 32 threads is the fastest setting for this op chain on the GPU box's 2 x EPYC 9575F (256 hw threads:
-        # 8 -> 2.1e7, 32 -> 2.6e7, 256 -> 1.6e6 pt*px/s; scripts/cpu_threads_probe.py), so that is the baseline.
-        torch.set_num_threads(min(os.cpu_count() or 1, 32))
-        K = {256: 64, 1024: 16, 2048: 8, 4096: 4}.get(pn, 8)
-        shifts = L.sourceShifts(w.bitmap, pn)
-        sel = shifts[(torch.arange(K, device=dev) * S_full) // K].cpu()
-        p_one = w.pupil if planes == 1 else w.pupil[planes // 2]
-        m_cpu, p_cpu = w.maskFT.cpu(), p_one.cpu()
-        O.abbe_raw(m_cpu, p_cpu, sel[:1], N)                        # warm-up
-        times = []
-        for _ in range(3):
-            c0 = time.perf_counter()
-            ref_raw = O.abbe_raw(m_cpu, p_cpu, sel, N)
-            times.append(time.perf_counter() - c0)
-        tmed = statistics.median(times)
-        # the parity sample runs the evaluation path of the TIMED step (a handful of points would otherwise fall below
-        # the coarse-grid path's source-count threshold and check the direct kernels instead)
-        old = os.environ.get("LITHO_ABBE_COARSE")
-        os.environ["LITHO_ABBE_COARSE"] = "2" if plan.get("coarse_grid") else "0"
-        try:
-            gpu_raw = L.abbeIntensity(w.maskFT, p_one, sel.to(dev), N).cpu()
-            parity_plan = nat.last_plan()
-        finally:
-            if old is None:
-                del os.environ["LITHO_ABBE_COARSE"]
-            else:
-                os.environ["LITHO_ABBE_COARSE"] = old
-        assert parity_plan["coarse_grid"] == plan.get("coarse_grid"), (parity_plan, plan)
-        parity = float((gpu_raw - ref_raw).abs().max() / ref_raw.max())
-        out["cpu_baseline"] = {"value": K * pn * pn / tmed, "unit": "source-pt*px/s", "cores": torch.get_num_threads(),
-                               "kind": "port",
-                               "sample": f"{K} source points strided through the {S_full}-point list, full {pn}x{pn} grid"
-                                         + (f", plane {planes // 2} of {planes}" if planes > 1 else "") +
-                                         f", 1 warm-up + 3 reps, median {tmed:.2f} s; oracle/abbe_oracle.py abbe_raw "
-                                         "(torch-CPU roll/mul/pad/fftshift/ifft2/ifftshift/crop/abs2/add)",
-                               "gpu_vs_cpu_rel_to_max": parity,
-                               "parity_path": {"coarse_grid": parity_plan["coarse_grid"], "kernels": list(nat.last_kernels())}}
+        out["cpu_baseline"] = cpu_baseline(torch, nat, w, plan, full=(args.workload == "cfg1"))
 
     # ---- every other BASELINE configuration, one or two timed steps each (default single-GPU run only)
     if world == 1 and not args.no_extra and args.workload == "cfg3" and not args.shard and args.points == 0:
@@ -488,7 +514,7 @@ def main():
                          ("cfg4", dict(shard=(0, 8), steps=1, warm_points=600, profile_points=600)),
                          ("cfg5", dict(steps=1, warm_points=240, profile_points=240))):
             try:
-                extras.append(extra_workload(torch, nat, dev, name, **kw))
+                extras.append(extra_workload(torch, nat, dev, name, cpu=not args.no_cpu_baseline, **kw))
             except Exception as exc:                              # an extra must never cost the headline line
                 extras.append({"workload": name, "error": repr(exc)})
         out["extra_workloads"] = extras

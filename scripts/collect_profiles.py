@@ -28,5 +28,14 @@ for p in sorted(glob.glob(os.path.join(src, "traffic_cfg*.json"))):
     except Exception as exc:
         print("skipped", p, exc)
 if traffic:
+    import subprocess
+    try:
+        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+        if subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "lithographysimulator_amd"], text=True).strip():
+            commit += "+uncommitted"
+    except Exception:
+        commit = None
+    for v in traffic.values():
+        v["commit"] = commit          # the source tree the counters were captured from (this script runs right after the capture)
     json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     print("traffic.json:", {k: (round(v["xpass_bytes_per_item"] / 1e6, 2), round(v["ypass_bytes_per_item"] / 1e6, 2)) for k, v in traffic.items()})

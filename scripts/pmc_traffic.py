@@ -46,6 +46,9 @@ out = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) ove
                   "gfx950 note in MI355X_MICROARCH.md (upper bound for 8-byte loads)",
        "items": items_total}
 for cls in ("xpass", "ypass"):
+    # the kernel the counters belong to, as the library names it in the same bench line (bench.py drops the entry when a
+    # later build launches another kernel for this workload)
+    out[cls + "_kernel"] = bench["roofline"]["kernels"][cls]["kernel"]
     out[cls + "_fetch_KiB_per_item"] = fetch[cls] / items_total
     out[cls + "_write_KiB_per_item"] = write[cls] / items_total
     out[cls + "_bytes_per_item"] = (2 * fetch[cls] + write[cls]) * 1024 / items_total

@@ -477,6 +477,46 @@ def test_contiguous_shard_vs_golden(golden, L, dev, monkeypatch, tag, pn, skind,
     assert abs(float(raw.double().sum()) / float(g[f"{tag}_raw_sum"]) - 1) < 2e-6
 
 
+@pytest.mark.parametrize("path", ["coarse", "direct"])
+def test_config3_long_consecutive_run_vs_golden(golden, L, dev, path):
+    """BASELINE config 3 at its DEFAULT launch geometry on the reference's dense data (golden g13): 1,536 consecutive
+    source points [60000, 61536) of the 2048^2 quasar list, accumulated by the reference's own abbeImage -- 128 batches of
+    the planner's 12-point batch, i.e. two 64-batch slab folds plus the final one, so the two-level summation is compared
+    with the reference's sequential fp32 loop.  Raw and post-processed image: centre crop, a stride-16 grid over the whole
+    image, every row / column sum, maximum, total; plan and kernel names asserted."""
+    from lithographysimulator_amd import _native as nat
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    g = golden("g13_config3_long_run.npz")
+    pn = 2048
+    lo, hi, S = (int(v) for v in g["cfg3run_range"])
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateQuasar(4, -math.pi / 8), pn)
+    assert sh.shape[0] == S == 198108
+    sel = sh[lo:hi]
+    assert np.array_equal(sel[[0, -1]].cpu().numpy(), g["cfg3run_first_last_shift"])
+    pf = L.Pupil(pn, WL, NA, f16(DEMO_AB), dev).generatePupilFunction()
+    raw = L.abbeIntensity(mft, pf, sel, N, options={"coarse": 1 if path == "coarse" else 0})       # 1 = the default rule
+    plan = nat.last_plan()
+    kx, ky = nat.last_kernels()
+    assert plan["coarse_grid"] == (1 if path == "coarse" else 0) and plan["batch"] == 12 and plan["launches"] == 128, plan
+    assert (kx, ky) == (("k_xpass_abbe<11, 0, true, 1, 1>", "k_ypass_rect<11, 8, true, 2>") if path == "coarse" else
+                        ("k_xpass_abbe<12, 1, true, 1, 1>", "k_ypass_wave<12, 8, false>")), (kx, ky)
+    final = L.postProcess(raw, eps).cpu()
+    raw = raw.cpu()
+    for tag, img in (("raw", raw), ("final", final)):
+        mx = float(g[f"cfg3run_{tag}_max"])
+        e_crop = rel_max(crop_center(img), g[f"cfg3run_{tag}_crop"])
+        e_grid = float(np.abs(img[::16, ::16].numpy().astype(np.float64) - g[f"cfg3run_{tag}_stride16"]).max() / mx)
+        print(f"2048^2 run of {hi - lo} points, {path} path, {tag}: crop {e_crop:.2e}, stride-16 grid {e_grid:.2e} (rel to max)")
+        assert e_crop < TOL_IMAGE_MAX and e_grid < TOL_IMAGE_MAX
+        assert np.allclose(img.double().sum(1).numpy(), g[f"cfg3run_{tag}_rowsum"], rtol=2e-5, atol=2e-6 * float(g[f"cfg3run_{tag}_rowsum"].max()))
+        assert np.allclose(img.double().sum(0).numpy(), g[f"cfg3run_{tag}_colsum"], rtol=2e-5, atol=2e-6 * float(g[f"cfg3run_{tag}_colsum"].max()))
+        assert abs(float(img.max()) / mx - 1) < 2e-5
+        assert abs(float(img.double().sum()) / float(g[f"cfg3run_{tag}_sum"]) - 1) < 2e-6
+
+
 @pytest.mark.parametrize("path", ["coarse", "direct", "coarse-tile8", "coarse-tile8-rowpairs", "coarse-default-batch", "direct-default-batch"])
 def test_consecutive_shard_4096_vs_golden(golden, L, dev, monkeypatch, path):
     """BASELINE config 4's size: 64 CONSECUTIVE source points [800000, 800064) of the 4096^2 annular list, run by the
@@ -624,6 +664,96 @@ def test_planned_call_is_capturable_in_a_hip_graph(L, dev, pn):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, e2) and not torch.equal(e1, e2)
+
+
+def test_graph_replay_survives_other_sizes_and_workspace_eviction(L, dev, monkeypatch):
+    """A captured graph holds raw pointers into the engine workspace.  The PlanCache it was captured through owns that
+    workspace: computing images of OTHER sizes between replays -- even with the process-wide workspace cache squeezed so
+    that it evicts everything it can -- must neither free nor reuse it (round-3 advice: the cache used to free the one
+    live workspace on the first call of another size, and a later replay scribbled over reallocated memory)."""
+    from lithographysimulator_amd import _native as nat
+    from lithographysimulator_amd.synthetic import bernoulli_mask, lines_mask
+    pn = 256
+    bm = L.LightSource(0.0, 0.5, pn, NA, device=dev).generateAnnular()
+    pf = L.Pupil(pn, WL, NA, f16(DEMO_AB), dev).generatePupilFunction()
+    m1, m2 = L.Mask(bernoulli_mask(pn), PS, dev), L.Mask(lines_mask(pn), PS, dev)
+    f1, f2 = m1.fraunhofer(WL, True), m2.fraunhofer(WL, True)
+    cache = L.PlanCache()
+    e1 = L.abbeImage(m1, f1, pf, bm, PS, m1.deltaK, WL, True, dev, plan_cache=cache)
+    e2 = L.abbeImage(m2, f2, pf, bm, PS, m2.deltaK, WL, True, dev, plan_cache=cache)
+    static = f1.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        L.abbeImage(m1, static, pf, bm, PS, m1.deltaK, WL, True, dev, plan_cache=cache)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = L.abbeImage(m1, static, pf, bm, PS, m1.deltaK, WL, True, dev, plan_cache=cache)
+    ws_ptr = cache.workspace.data_ptr()
+    monkeypatch.setattr(nat, "WORKSPACE_CACHE_BYTES", 1)          # every new size evicts all the cache may evict
+    hogs = []
+    for other in (512, 128, 1024):
+        mk = L.Mask(bernoulli_mask(other), PS, dev)
+        b = L.LightSource(0.0, 0.5, other, NA, device=dev).generateAnnular()
+        p = L.Pupil(other, WL, NA, None, dev).generatePupilFunction()
+        img = L.abbeImage(mk, mk.fraunhofer(WL, True), p, b if other < 1024 else subsample_bitmap(b.cpu(), 64).to(dev), PS,
+                          mk.deltaK, WL, True, dev)
+        assert bool(torch.isfinite(img).all())
+        hogs.append(torch.full((64 << 20,), 7, dtype=torch.uint8, device=dev))   # would land on a freed workspace first
+    assert len([k for k in nat._workspaces if k[0] == dev.index]) == 1 and cache.workspace.data_ptr() == ws_ptr
+    for h in hogs:
+        h.fill_(255)                                              # NaN patterns wherever freed memory was handed out
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, e1)
+    static.copy_(f2)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, e2)
+    assert all(bool((h == 255).all()) for h in hogs)             # and the replay wrote into none of them
+
+
+def test_plan_cache_notices_another_pupil_or_source(L, dev):
+    """Round-3 advice: a PlanCache reused with a DIFFERENT pupil tensor (a wider support box: the recorded box would
+    prune live rows), an in-place edit of the same tensor, or another source bitmap used to give a silently wrong image.
+    The cache now remembers which tensors it was made for (address, shape, version counter -- host-side only) and plans
+    afresh; unchanged tensors keep the no-wait path; plan_cache with group= is refused."""
+    from lithographysimulator_amd import _native as nat
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    pn = 256
+    mk = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mk.fraunhofer(WL, True)
+    bm = L.LightSource(0.0, 0.5, pn, NA, device=dev).generateAnnular()
+    bm2 = L.LightSource(0.3, 0.7, pn, NA, device=dev).generateAnnular()
+    pf = L.Pupil(pn, WL, NA, f16(DEMO_AB), dev).generatePupilFunction()
+    wide = pf.clone()
+    wide[pn // 2 - 3:pn // 2 + 3, pn // 2 + pn // 4 + 1:pn // 2 + pn // 4 + 30] = 0.5 + 0.5j     # beyond the recorded box
+    img = lambda p, b, **kw: L.abbeImage(mk, mft, p, b, PS, mk.deltaK, WL, True, dev, **kw)      # noqa: E731
+    cache = L.PlanCache()
+    assert torch.equal(img(pf, bm, plan_cache=cache), img(pf, bm)) and nat.last_plan()["planned_from_record"] == 0
+    assert torch.equal(img(pf, bm, plan_cache=cache), img(pf, bm))
+    img(pf, bm, plan_cache=cache)
+    assert nat.last_plan()["planned_from_record"] == 1                                          # unchanged: no-wait path
+    got = img(wide, bm, plan_cache=cache)                                                        # another pupil tensor
+    assert nat.last_plan()["planned_from_record"] == 0 and torch.equal(got, img(wide, bm))
+    assert not torch.equal(got, img(pf, bm))
+    got = img(wide, bm2, plan_cache=cache)                                                       # another source bitmap
+    assert nat.last_plan()["planned_from_record"] == 0 and cache.S == int(bm2.sum()) and torch.equal(got, img(wide, bm2))
+    img(wide, bm2, plan_cache=cache)
+    assert nat.last_plan()["planned_from_record"] == 1
+    wide[pn // 2 + pn // 4 + 5, pn // 2] = 1.0                                                   # in-place edit, same tensor
+    got = img(wide, bm2, plan_cache=cache)
+    assert nat.last_plan()["planned_from_record"] == 0 and torch.equal(got, img(wide, bm2))
+    # the explicit-list form
+    eps, N = mk.calculateEpsilonN(mk.deltaK, PS, WL)
+    sh, sh2 = L.sourceShifts(bm, pn), L.sourceShifts(bm2, pn)
+    c2 = L.PlanCache()
+    L.abbeIntensity(mft, pf, sh, N, plan=c2)
+    a, S = L.abbeIntensity(mft, wide, sh2, N, plan=c2)
+    assert nat.last_plan()["planned_from_record"] == 0 and S == sh2.shape[0] and torch.equal(a, L.abbeIntensity(mft, wide, sh2, N))
+    with pytest.raises(ValueError):
+        L.abbeImage(mk, mft, pf, bm, PS, mk.deltaK, WL, True, dev, plan_cache=cache, group=object())
 
 
 @pytest.mark.parametrize("path", ["coarse", "direct"])

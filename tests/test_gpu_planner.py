@@ -57,6 +57,24 @@ def _strided_points(L, dev, pn, K, sin=0.4, sout=0.8):
     return sh[(torch.arange(K, device=dev) * sh.shape[0]) // K].contiguous()
 
 
+def _oracle_chunked(o, mft, pupil, shifts, N, workers=16):
+    """oracle.abbe_raw (the reference's op chain, sequential fp32 per chunk) over `workers` contiguous chunks of the list on a
+    thread pool (torch's CPU ops release the GIL), partial images added in float64: the same sum to ~1e-7, in a sixteenth
+    of the time -- the oracle's FFTs at these sizes run on one core each."""
+    from concurrent.futures import ThreadPoolExecutor
+    S = shifts.shape[0]
+    bounds = [(i * S) // workers for i in range(workers + 1)]
+    chunks = [shifts[a:b] for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
+    old = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            parts = list(pool.map(lambda sh: o.abbe_raw(mft, pupil, sh, N).double(), chunks))
+    finally:
+        torch.set_num_threads(old)
+    return torch.stack(parts).sum(0)
+
+
 def _check(got, ref, what):
     e, l2 = rel_max(got, ref), rel_l2(got, ref)
     print(f"{what}: rel-to-max {e:.2e}, rel-L2 {l2:.2e}")
@@ -180,7 +198,7 @@ def test_support_box_one_sample_inside_and_outside_the_natural_box(L, dev, pn, s
 @pytest.mark.parametrize("pn,s_min", [(512, 1536), (1024, 384)])
 def test_source_count_threshold_of_the_coarse_grid(L, dev, pn, s_min):
     """Default mode (coarse = 1): S = s_min - 1 stays on the direct path, S = s_min takes the coarse grid; both are the
-    reference's image (the oracle's sequential fp32 loop over the same consecutive points)."""
+    reference's image (the oracle's op chain over the same consecutive points)."""
     o = O()
     N = 2 * pn
     mft = _mask_spectrum(L, dev, pn)
@@ -188,8 +206,8 @@ def test_source_count_threshold_of_the_coarse_grid(L, dev, pn, s_min):
     sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateAnnular(), pn)
     lo = sh.shape[0] // 3
     sel = sh[lo:lo + s_min].contiguous()
-    ref_short = o.abbe_raw(mft.cpu(), pupil.cpu(), sel[:-1].cpu(), N)
-    ref_full = ref_short + o.abbe_raw(mft.cpu(), pupil.cpu(), sel[-1:].cpu(), N)
+    ref_short = _oracle_chunked(o, mft.cpu(), pupil.cpu(), sel[:-1].cpu(), N)
+    ref_full = ref_short + o.abbe_raw(mft.cpu(), pupil.cpu(), sel[-1:].cpu(), N).double()
     for S, ref, expect in ((s_min - 1, ref_short, 0), (s_min, ref_full, 1)):
         got = L.abbeIntensity(mft, pupil, sel[:S].contiguous(), N, options={"coarse": 1}).cpu()
         plan = nat().last_plan()
@@ -225,7 +243,7 @@ def test_shift_one_sample_short_of_wrapping_and_one_past(L, dev, pn, axis, sign)
 
 
 # ------------------------------------------------------------------ seeded fuzz
-FUZZ_CASES = 240
+FUZZ_CASES = 320
 
 
 def _fuzz_pupil(gen, kind, pn):
@@ -274,14 +292,14 @@ def _fuzz_case(seed):
     gen = torch.Generator().manual_seed(900000 + seed)
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=gen))          # noqa: E731
     pick = lambda seq: seq[ri(0, len(seq) - 1)]                                      # noqa: E731
-    pn = pick([64, 96, 128, 256, 256, 512])
-    ps = pick([25, 25, 10, 48])
-    kind = pick(["disk", "disk", "disk_rim", "disk_junk", "box", "box", "single", "full", "empty"])
+    pn = pick([64, 96, 128, 256, 256, 256, 512, 512])
+    ps = pick([25, 25, 25, 10, 48])
+    kind = pick(["disk", "disk", "disk", "disk_rim", "disk_rim", "disk_junk", "disk_junk", "box", "box", "single", "full", "empty"])
     planes = pick([1, 1, 1, 2, 3, 5])
     budget = {64: 40, 96: 30, 128: 24, 256: 12, 512: 5}[pn]                          # source points x planes the oracle gets
     S = max(1, min(ri(1, 14), budget // planes))
     c, h = pn // 2, pn // 4
-    mode = pick(["narrow", "narrow", "wide", "wrap"])
+    mode = pick(["narrow", "narrow", "narrow", "wide", "wide", "wrap"])
     lim = {"narrow": max(1, int(0.2 * pn)), "wide": c - h, "wrap": c}[mode]
     sh = torch.randint(-lim, lim + (0 if mode == "wrap" else 1), (S, 2), generator=gen, dtype=torch.int32)
     if S > 2 and ri(0, 1):

@@ -48,26 +48,29 @@ def test_bench_json_contract():
     assert "extra_workloads" not in r                           # only the default cfg3 run carries them
 
 
-def test_bench_launches_its_own_ranks():
-    """`python bench.py --gpus 2` as a PLAIN process (no torch.distributed.run, no WORLD_SIZE) must start the ranks
-    itself (fresh children; the parent never touches the GPU) and relay rank 0's JSON line.  The test box has one
-    GPU and RCCL refuses two ranks on one device, so the two ranks share cuda:0 over a gloo group
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_launches_its_own_ranks(world):
+    """`python bench.py --gpus N` as a PLAIN process (no torch.distributed.run, no WORLD_SIZE) must start the ranks
+    itself (fresh children; the parent never touches the GPU) and relay rank 0's JSON line -- N = 2, and N = 8: the node
+    size north_star names, with S = 3233 not divisible by 8.  The test box has one
+    GPU and RCCL refuses two ranks on one device, so the ranks share cuda:0 over a gloo group
     (LITHO_BENCH_SHARE_GPU / LITHO_BENCH_BACKEND): everything else -- rendezvous on 127.0.0.1, source-point shards,
     the all-reduce inside abbeImage, barrier + max-over-ranks timing -- is the code the 8-GPU run executes."""
     env = dict(os.environ, LITHO_BENCH_SHARE_GPU="1", LITHO_BENCH_BACKEND="gloo")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cfg1", "--steps", "2",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--workload", "cfg1", "--steps", "2",
                           "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     r = json.loads(lines[0])
-    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["config"]["points_per_rank"] == 1617
+    shards = [1617, 1616] if world == 2 else [405] + [404] * 7     # contiguous balanced shards (distributed.shard_bounds)
+    assert r["n_gpus"] == world and r["scaling"] == "strong" and r["config"]["points_per_rank"] == shards[0]
     assert r["config"]["source_points"] == 3233 and r["value"] > 1e9 and "cpu_baseline" not in r
-    assert r["config"]["parallelism"].startswith("source-point shards x2")
+    assert r["config"]["parallelism"].startswith(f"source-point shards x{world}")
     rk = r["ranks"]                                               # per-rank view of one instrumented step
-    assert len(rk["step_ms"]) == 2 and len(rk["compute_ms"]) == 2 and len(rk["allreduce_wait_ms"]) == 2
-    assert rk["source_points"] == [1617, 1616] and rk["allreduce_bytes"] == 256 * 256 * 4
+    assert len(rk["step_ms"]) == world and len(rk["compute_ms"]) == world and len(rk["allreduce_wait_ms"]) == world
+    assert rk["source_points"] == shards and sum(shards) == 3233 and rk["allreduce_bytes"] == 256 * 256 * 4
     assert rk["step_ms_max"] >= rk["step_ms_min"] > 0 and min(rk["compute_ms"]) > 0
 
 

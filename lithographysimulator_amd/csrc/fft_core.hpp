@@ -20,7 +20,7 @@
 // litho_target_arch() == "gfx950-diag", which the Python binding and __graft_entry__.build() refuse.
 #if (defined(LITHO_DIAG_NOBARRIER) || defined(LITHO_DIAG_NOLDSWRITE) || defined(LITHO_DIAG_NOLDSREAD) ||   \
      defined(LITHO_DIAG_XNOLOAD) || defined(LITHO_DIAG_XNOSTORE) || defined(LITHO_DIAG_XSTORE_L2) ||       \
-     defined(LITHO_DIAG_YNOLOAD)) &&                                                                       \
+     defined(LITHO_DIAG_YNOLOAD) || defined(LITHO_DIAG_YFLUSH_STORE) || defined(LITHO_DIAG_YFLUSH_NONE)) &&                                                                       \
     !defined(LITHO_DIAG_BUILD)
 #error "LITHO_DIAG_* switches produce wrong results; use scripts/build_variants.sh (defines LITHO_DIAG_BUILD, separate output)"
 #endif

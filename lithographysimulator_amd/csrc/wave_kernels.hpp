@@ -508,7 +508,13 @@ __global__ __launch_bounds__(256 * GW, 2) void k_ypass_rect(
         constexpr int i = decltype(i_)::value;
         constexpr int k2 = kept_k2(i);
         constexpr int ubase = k2 < S / 2 ? H * k2 : H * k2 - N;             // bin u = m + H k2 (mod N, centred)
+#if defined(LITHO_DIAG_YFLUSH_STORE)                                          // timing diagnostics (wrong results): a write-only flush,
+        srow[ubase + m + g.c] = acc[i];
+#elif defined(LITHO_DIAG_YFLUSH_NONE)                                         // and none at all (accumulators that never leave the registers)
+        if (acc[i] == 12345.678f) srow[ubase + m + g.c] = acc[i];
+#else
         srow[ubase + m + g.c] += acc[i];
+#endif
     });
 }
 

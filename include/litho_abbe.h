@@ -140,7 +140,6 @@ typedef struct litho_abbe_options {
     int32_t w64, rect, w64_8192, xsplit, xrect, w64x, gcombine, rowpairs;   /* kernel families, DESIGN.md section 8 */
     int32_t force_generic, force_general;                                  /* runtime-predicated kernels / modular gather */
     int32_t poison;          /* 1: scratch starts the call as NaN bit patterns (tests) */
-    int32_t xstorewave;      /* 1: coarse-grid x-pass with a dedicated store wave per workgroup (k_xpass_abbe_sw) */
 } litho_abbe_options;
 int litho_abbe_accumulate_opts(const void *maskFT, const void *pupil, int planes, const int32_t *shifts,
                                const int32_t *count_dev, int64_t capacity, int pn, int N, float *out,

@@ -376,7 +376,7 @@ static int env_int(const char* name, int dflt)
 // Tuning / test knobs.  Resolved ONCE per C-ABI call, never per launch: a field of the caller's litho_abbe_options that is
 // >= 0 wins, otherwise the LITHO_ABBE_* environment variable, otherwise the default.
 struct Knobs {
-    int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk, xsplit, rect, xrect, coarse, gcombine, rowpairs, poison, xstorewave;
+    int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk, xsplit, rect, xrect, coarse, gcombine, rowpairs, poison;
     static int pick(const litho_abbe_options* o, size_t off, const char* name, int dflt)
     {
         if (o && off + sizeof(int32_t) <= (size_t)o->size) {
@@ -406,7 +406,6 @@ struct Knobs {
         LITHO_KNOB(gcombine, "LITHO_ABBE_GCOMBINE", 1);
         LITHO_KNOB(rowpairs, "LITHO_ABBE_ROWPAIRS", 0);
         LITHO_KNOB(poison, "LITHO_ABBE_POISON", 0);
-        LITHO_KNOB(xstorewave, "LITHO_ABBE_XSTOREWAVE", 0);
 #undef LITHO_KNOB
         return k;
     }
@@ -480,7 +479,7 @@ static void make_geom(PassGeom& g, int pn, int N, int r0, int c0, int h, int wdt
     g.pn = pn; g.c = pn / 2; g.N = N; g.nt = (pn + 3) / 4;
     g.kx0 = c0 - g.c; g.kx1 = c0 + wdt - g.c;
     g.ky0 = r0 - g.c; g.ky1 = r0 + h - g.c;
-    g.rows = h; g.general = general; g.rect_off = 0; g.gcombine = 0; g.row_pairs = 0; g.store_wave = 0;
+    g.rows = h; g.general = general; g.rect_off = 0; g.gcombine = 0; g.row_pairs = 0;
     g.xmask = slot_mask(N, g.kx0, g.kx1);
     g.ymask = slot_mask(N, g.ky0, g.ky1);
     set_tile(g, h, tile_cols);
@@ -563,8 +562,6 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
     g.rect_off = rect ? 0 : 1;
     g.gcombine = kn.gcombine ? 1 : 0;
     g.row_pairs = (kn.rowpairs && g.tcl == 3) ? 1 : 0;
-    // coarse-grid x-pass with a dedicated store wave (k_xpass_abbe_sw: N = pn = 1024 .. 4096, natural box, one plane per launch)
-    g.store_wave = (kn.xstorewave && variant == 0 && pn == N && natural_box && N >= 1024 && N <= 4096 && g.tcl >= 3) ? 1 : 0;
     const bool wave_y = w64_shape && (g.tcl == 2 || g.tcl == 3 || (g.tcl == 4 && N == 4096 && variant == 0)) && ((N != 512 && N != 256) || rect) &&
                         (variant == 1 || rect || N == 4096);
 
@@ -793,7 +790,7 @@ static int reconstruct_plane(const SizeOps* ops, const SizeOps* ops_c, const Wor
     PassGeom gf;
     gf.pn = pn; gf.c = pn / 2; gf.N = pn; gf.nt = (pn + 3) / 4;
     gf.kx0 = -pn / 2; gf.kx1 = pn / 2; gf.ky0 = gf.kx0; gf.ky1 = gf.kx1;
-    gf.rows = pn; gf.general = 0; gf.rect_off = 0; gf.gcombine = 0; gf.row_pairs = 0; gf.store_wave = 0;
+    gf.rows = pn; gf.general = 0; gf.rect_off = 0; gf.gcombine = 0; gf.row_pairs = 0;
     gf.xmask = slot_mask(pn, gf.kx0, gf.kx1); gf.ymask = gf.xmask;
     set_tile(gf, gf.rows);
     RealImageLoader ldr{ic, pn, 0, nullptr};
@@ -1001,7 +998,7 @@ static int mask_spectrum(const int16_t* geo, int pn, double eps, int N, float2* 
     g.pn = pn; g.c = pn / 2; g.N = N; g.nt = (int)nt;
     g.kx0 = j0 - N / 2; g.kx1 = j1 - N / 2;
     g.ky0 = g.kx0; g.ky1 = g.kx1;
-    g.rows = j1 - j0; g.general = 0; g.rect_off = 0; g.gcombine = 0; g.row_pairs = 0; g.store_wave = 0;
+    g.rows = j1 - j0; g.general = 0; g.rect_off = 0; g.gcombine = 0; g.row_pairs = 0;
     g.xmask = slot_mask(N, g.kx0, g.kx1);
     g.ymask = slot_mask(N, g.ky0, g.ky1);
     set_tile(g, g.rows);

@@ -31,7 +31,6 @@ struct PassGeom {
     int gcombine;           // 1: k_ypass_rect puts the two groups of a column block into ONE workgroup and combines their
                             //    accumulators through LDS before the slab flush (half the flush traffic)
     int row_pairs;          // 1: an x-pass workgroup takes two adjacent rows (N = pn = 4096: T streams through HBM, see k_xpass_abbe)
-    int store_wave;         // 1: coarse-grid x-pass with a dedicated store wave per workgroup (k_xpass_abbe_sw, opt-in)
     unsigned xmask, ymask;  // bit e set: slot e can be non-zero for SOME thread (x / y input)
     long long t_point;      // float2 elements of T per source point = ceil(pn/tc)*rows*tc
 };
@@ -303,115 +302,6 @@ __global__ __launch_bounds__(Launch<LOG2N>::THREADS, (RP == 2 ? Launch<LOG2N>::W
                 }
             });
         });
-    }
-}
-
-// ----------------------------------------------------------------------------------
-// Coarse-grid x-pass (N = pn: every bin kept) with a DEDICATED STORE WAVE per workgroup (opt-in: options.xstorewave /
-// LITHO_ABBE_XSTOREWAVE; round-4 experiment).  k_xpass_abbe's transform waves issue their 16 T stores per lane in one burst
-// at the end of every row; at 2048^2 the kernel then takes 48-50 us per 12-item batch although its arithmetic + loads
-// alone take 36 and its stores alone 30.  Here the F::T transform threads hand a finished row
-// to a staging row in LDS instead (8-byte ds_write, conflict free) and a 65th .. wave drains it into T WHILE THE NEXT
-// ITEM IS TRANSFORMED: it owns no transform work, reads the row back 16 bytes per lane and issues a quarter of the row's
-// stores in each of the FFT's four barrier intervals, so that stores leave the CU at an even rate and a full store
-// queue stalls nobody who has arithmetic to do.  All waves of the workgroup meet at the same s_barriers: the FFT's
-// 2 x EXCH LDS barriers per item plus one hand-over barrier.
-// ----------------------------------------------------------------------------------
-template <int LOG2N>
-__global__ __launch_bounds__(Launch<LOG2N>::THREADS + 64, Launch<LOG2N>::WAVES) void k_xpass_abbe_sw(
-    const float2* __restrict__ P, const float2* __restrict__ M, const int* __restrict__ shifts,
-    float2* __restrict__ Tbuf, const float2* __restrict__ twtab, PassGeom g, int nb, int chunk)
-{
-    using F = LineFFT<LOG2N, +1>;
-    using LC = Launch<LOG2N>;
-    static_assert(LC::L == 1 && LC::NBUF == 1 && F::T >= 64, "one row per workgroup, one exchange buffer");
-    constexpr unsigned IN = natural_in_mask(0);
-    constexpr int SLOTS = 2 * F::EXCH;                       // barrier intervals of one transform
-    constexpr int NI = F::N / 128;                           // 16-byte store instructions of the store wave per row
-    static_assert(NI % SLOTS == 0, "the row's stores split evenly over the barrier intervals");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2* smem = reinterpret_cast<float2*>(smem_raw);
-    float2* stg = smem + LC::LDS_EXCH + F::LDS_TW + ((LC::LDS_EXCH + F::LDS_TW) & 1);      // 16-byte aligned staging row: pn float2
-    const bool storer = threadIdx.x >= F::T;
-    const int lt = threadIdx.x & (F::T - 1);
-    const int bx = blockIdx.x, xcd = bx & 7, bi = bx >> 3;
-    const int a = (bi >> 2) * 32 + xcd * 4 + (bi & 3);       // XCD-aware row mapping, see k_xpass_abbe
-    if (a >= g.rows) return;                                 // (uniform per workgroup, before any barrier)
-    typename F::Twiddles tw;
-    F::load_twiddles(tw, twtab, lt, smem + LC::LDS_EXCH, threadIdx.x, LC::THREADS + 64);
-    const int s_begin = blockIdx.y * chunk;
-    const int s_end = min(nb, s_begin + chunk);
-
-    if (storer) {
-        const int sl = threadIdx.x - F::T;
-        const unsigned off0 = t_offset(g, (unsigned)a, 2u * (unsigned)sl) * 8u;
-        const unsigned stride = (unsigned)g.rows * 1024u;    // 128 columns further = 128 >> tcl tiles of rows * (8 << tcl) bytes
-        const u32x4* src = reinterpret_cast<const u32x4*>(stg) + sl;
-        auto drain = [&](int s, auto k_) {
-            constexpr int k = decltype(k_)::value;
-            const __amdgpu_buffer_rsrc_t rT = make_rsrc(Tbuf + (size_t)s * g.t_point, (size_t)g.t_point * sizeof(float2));
-            static_for<0, NI / SLOTS>([&](auto jj_) {
-                constexpr int j = k * (NI / SLOTS) + decltype(jj_)::value;
-                const u32x4 v = src[64 * j];
-                __builtin_amdgcn_raw_buffer_store_b128(v, rT, off0 + (unsigned)j * stride, 0, t_store_aux<LOG2N>);
-            });
-        };
-        for (int s = s_begin; s < s_end; ++s) {
-            static_for<0, SLOTS>([&](auto k_) {
-                if (s > s_begin) drain(s - 1, k_);
-                lds_barrier();
-            });
-            lds_barrier();                                   // hand-over: row s is in the staging buffer
-        }
-        if (s_begin < s_end) static_for<0, SLOTS>([&](auto k_) { drain(s_end - 1, k_); });
-        return;
-    }
-
-    float2* lds = smem;
-    const int r = g.ky0 + g.c + a;
-    const size_t plane_bytes = (size_t)g.pn * g.pn * sizeof(float2);
-    const __amdgpu_buffer_rsrc_t rM = make_rsrc(M, plane_bytes);
-    const __amdgpu_buffer_rsrc_t rP = make_rsrc(P, plane_bytes);
-    unsigned koff[16];
-    float2 pv[16];
-    static_for<0, 16>([&](auto e_) {
-        constexpr int e = decltype(e_)::value;
-        if constexpr ((IN >> e) & 1u) {
-            int k;
-            const bool ok = centred_index(lt + F::T * e, F::N, g.kx0, g.kx1, k);
-            koff[e] = ok ? (unsigned)(g.c + k) : BUF_OOB;
-            pv[e] = buf_load_c64(rP, ok ? ((unsigned)r * g.pn + koff[e]) * 8u : BUF_OOB);
-        }
-    });
-    // staging slot of output bin n = lt + T m: column q = u + c with u the centred bin; N = pn, c = N/2, so q = (n + N/2) mod N
-    // = lt + T (m ^ 8): one base register + immediates, consecutive lanes on consecutive 8-byte slots
-    float2* const sb = stg + lt;
-    auto load_window = [&](int s, float2 (&mv)[16]) {
-        const int dy = shifts[2 * s], dx = shifts[2 * s + 1];
-        const unsigned mrow = (unsigned)(r + dy) * g.pn + dx;
-        static_for<0, 16>([&](auto e_) {
-            constexpr int e = decltype(e_)::value;
-            if constexpr ((IN >> e) & 1u) mv[e] = buf_load_c64(rM, koff[e] != BUF_OOB ? (mrow + koff[e]) * 8u : BUF_OOB);
-        });
-    };
-    int flip = 0;
-    float2 mnext[16];
-    if (s_begin < s_end) load_window(s_begin, mnext);
-    static_for<0, 16>([&](auto e_) {
-        constexpr int e = decltype(e_)::value;
-        if constexpr ((IN >> e) & 1u) touch_vgpr(mnext[e]);   // see k_xpass_abbe: no vmcnt(0) in the loop header
-    });
-    for (int s = s_begin; s < s_end; ++s) {
-        float2 x[16];
-        static_for<0, 16>([&](auto e_) {
-            constexpr int e = decltype(e_)::value;
-            if constexpr ((IN >> e) & 1u) x[e] = cmul(pv[e], mnext[e]);
-            else x[e] = make_float2(0.f, 0.f);
-        });
-        load_window(s + 1 < s_end ? s + 1 : s, mnext);
-        F::template run<1>(x, tw, lds, lt, flip);
-        static_for<0, 16>([&](auto m_) { constexpr int m = decltype(m_)::value; sb[F::T * (m ^ 8)] = x[m]; });
-        lds_barrier();                                       // hand-over
     }
 }
 
@@ -932,32 +822,10 @@ struct SizeImpl {
         note_kernel(0, PRUNED ? "k_xpass_abbe<%d, %d, true, %d, %d>" : "k_xpass_abbe<%d, %d, false, %d, %d>", LOG2N, RL, NP, RP);   // as rocprofv3 prints it
         return hipGetLastError();
     }
-    static hipError_t xa_sw(const float2* P, const float2* M, const int* shifts, float2* T, const float2* tw,
-                            const PassGeom& g, int nb, int chunk, hipStream_t st)
-    {
-        if constexpr (LOG2N >= 10 && LOG2N <= 12) {
-            using F = LineFFT<LOG2N, +1>;
-            static LdsOnce once;
-            constexpr size_t base = (LC::LDS_EXCH + F::LDS_TW + ((LC::LDS_EXCH + F::LDS_TW) & 1)) * sizeof(float2);
-            constexpr size_t lds = base + (size_t)F::N * sizeof(float2);
-            auto kern = k_xpass_abbe_sw<LOG2N>;
-            hipError_t e = set_lds(once, kern, lds);
-            if (e != hipSuccess) return e;
-            dim3 grid((g.rows + 31) / 32 * 32, (nb + chunk - 1) / chunk);
-            hipLaunchKernelGGL(kern, grid, dim3(LC::THREADS + 64), lds, st, P, M, shifts, T, tw, g, nb, chunk);
-            note_kernel(0, "k_xpass_abbe_sw<%d>", LOG2N);
-            return hipGetLastError();
-        } else {
-            return hipErrorNotSupported;
-        }
-    }
     template <int RL>
     static hipError_t xa_np(int np, const float2* P, const float2* M, const int* shifts, float2* T, const float2* tw,
                             const PassGeom& g, int nb, int chunk, hipStream_t st)
     {
-        if constexpr (RL == 0 && LOG2N >= 10 && LOG2N <= 12) {
-            if (np == 1 && g.store_wave && g.N == g.pn && !g.row_pairs) return xa_sw(P, M, shifts, T, tw, g, nb, chunk, st);
-        }
         if constexpr (LOG2N == 12 && RL == 0) {
             if (np == 1 && g.row_pairs) return xa<RL, true, 1, 2>(P, M, shifts, T, tw, g, nb, chunk, st);
         }

@@ -129,27 +129,27 @@ __global__ void k_shift_extents(const int* __restrict__ shifts, long long S, con
     }
 }
 
-// out[p][qy][qx] += sum_g slab[p * gstride + g][qx][qy]   (32x32 tiles through LDS; blockIdx.z = plane p)
-__global__ void k_slab_reduce(const float* __restrict__ slab, float* __restrict__ out, int pn, int ldq, int G,
-                              int gstride)
+// out[p][qy][qx] += sum_g slab[p * gstride + g][qx][qy]   (32x32 tiles through LDS; blockIdx.z = plane p).  1024 threads per
+// tile, one element each: small images fold up to 64 slabs into a few dozen tiles (256^2: 64 tiles), and with 256 threads
+// walking four rows each that took 38 us per image; fixed summation order (deterministic).
+__global__ __launch_bounds__(1024) void k_slab_reduce(const float* __restrict__ slab, float* __restrict__ out, int pn, int ldq, int G,
+                                                      int gstride)
 {
     __shared__ float tile[32][33];
     slab += (size_t)blockIdx.z * gstride * ldq * pn;
     out += (size_t)blockIdx.z * pn * pn;
     const int qx0 = blockIdx.x * 32, qy0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 256 threads: ty in 0..7
-    for (int j = ty; j < 32; j += 8) {
-        const int qx = qx0 + j, qy = qy0 + tx;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 1024 threads: ty in 0..31
+    {
+        const int qx = qx0 + ty, qy = qy0 + tx;
         float v = 0.f;
         if (qx < pn && qy < pn)
             for (int gidx = 0; gidx < G; ++gidx) v += slab[((size_t)gidx * ldq + qx) * pn + qy];
-        tile[j][tx] = v;
+        tile[ty][tx] = v;
     }
     __syncthreads();
-    for (int j = ty; j < 32; j += 8) {
-        const int qy = qy0 + j, qx = qx0 + tx;
-        if (qx < pn && qy < pn) out[(size_t)qy * pn + qx] += tile[tx][j];
-    }
+    const int qy = qy0 + ty, qx = qx0 + tx;
+    if (qx < pn && qy < pn) out[(size_t)qy * pn + qx] += tile[tx][ty];
 }
 
 static constexpr int COARSE_PLANES = 4;                      // = the largest plane chunk
@@ -223,16 +223,30 @@ __global__ __launch_bounds__(256) void k_nyquist_edges(const float2* __restrict_
 }
 
 // gam layout: [GAM_PARTIAL partials][Gamma: 2 edges x 2 EDGE_MAX][profiles: 2 x pn]
-__global__ void k_nyquist_reduce(float2* __restrict__ gam, int chunks)
+// Sum of the per-chunk partial edge sums, in a fixed order (deterministic): a 256-thread block owns 8 consecutive kappa
+// indices x 32 chunk lanes (a chunk's 8 entries are one 64-byte run), every thread adds chunks / 32 partials, then the 32
+// lanes of an index fold by shuffles and one LDS step.  (Round 3's one-thread-per-index loop over up to 1024 chunks took
+// 268 us per image -- most of the coarse grid's fixed cost at 256^2; this one takes a few.)
+static constexpr int NYQ_RED_IDX = 8;
+__global__ __launch_bounds__(256) void k_nyquist_reduce(float2* __restrict__ gam, int chunks)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // edge * 2 EDGE_MAX + kappa index
-    if (idx >= 2 * 2 * EDGE_MAX) return;
+    __shared__ float2 part[4][NYQ_RED_IDX];
+    const int il = threadIdx.x & (NYQ_RED_IDX - 1), cl = threadIdx.x / NYQ_RED_IDX;      // chunk lane 0 .. 31
+    const int idx = blockIdx.x * NYQ_RED_IDX + il;              // edge * 2 EDGE_MAX + kappa index
     float2 a = make_float2(0.f, 0.f);
-    for (int ch = 0; ch < chunks; ++ch) {
+    for (int ch = cl; ch < chunks; ch += 256 / NYQ_RED_IDX) {
         const float2 v = gam[(size_t)ch * (2 * 2 * EDGE_MAX) + idx];
         a.x += v.x; a.y += v.y;
     }
-    gam[GAM_PARTIAL + idx] = a;
+    for (int off = NYQ_RED_IDX; off < 64; off <<= 1) { a.x += __shfl_xor(a.x, off); a.y += __shfl_xor(a.y, off); }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) < NYQ_RED_IDX) part[wv][il] = a;
+    __syncthreads();
+    if (threadIdx.x < NYQ_RED_IDX) {
+        float2 t = part[0][il];
+        for (int w = 1; w < 4; ++w) { t.x += part[w][il].x; t.y += part[w][il].y; }
+        gam[GAM_PARTIAL + idx] = t;
+    }
 }
 
 __global__ void k_nyquist_profiles(float2* __restrict__ gam, const float2* __restrict__ twtab, EdgeGeom eg, int N)
@@ -763,7 +777,7 @@ static int accumulate_chunk(const AbbePlan& pp, const SizeOps* ops, const Worksp
         // float64 sum of short runs: 5.4e-6 of the maximum with one slab sum over all 16,509 batches, see
         // scripts/accum_error_probe.py).  Costs one k_slab_reduce + memset per 64 launch pairs (< 0.5 %).
         if (++since_flush == SLAB_FLUSH_BATCHES && s0 + bs < S) {
-            hipLaunchKernelGGL(k_slab_reduce, dim3((pn + 31) / 32, (pn + 31) / 32, pc), dim3(256), 0, st,
+            hipLaunchKernelGGL(k_slab_reduce, dim3((pn + 31) / 32, (pn + 31) / 32, pc), dim3(1024), 0, st,
                                w.slab, dst, pn, g.nt * 4, pp.slabs, G);
             HIP_TRY(hipGetLastError());
             HIP_TRY(zero_slabs(w.slab, pc, G, pp.slabs, slab_plane, st));
@@ -771,7 +785,7 @@ static int accumulate_chunk(const AbbePlan& pp, const SizeOps* ops, const Worksp
             fresh = true;
         }
     }
-    hipLaunchKernelGGL(k_slab_reduce, dim3((pn + 31) / 32, (pn + 31) / 32, pc), dim3(256), 0, st,
+    hipLaunchKernelGGL(k_slab_reduce, dim3((pn + 31) / 32, (pn + 31) / 32, pc), dim3(1024), 0, st,
                        w.slab, dst, pn, g.nt * 4, pp.slabs, G);
     HIP_TRY(hipGetLastError());
     return LITHO_OK;
@@ -806,7 +820,7 @@ static int reconstruct_plane(const SizeOps* ops, const SizeOps* ops_c, const Wor
     if (eg.len[0] > 0 || eg.len[1] > 0) {
         const int chunks = (int)(S < GAM_CHUNKS ? S : GAM_CHUNKS);
         hipLaunchKernelGGL(k_nyquist_edges, dim3(chunks), dim3(256), 0, st, Pp, M, shifts, (long long)S, eg, w.gam);
-        hipLaunchKernelGGL(k_nyquist_reduce, dim3((2 * 2 * EDGE_MAX + 255) / 256), dim3(256), 0, st, w.gam, chunks);
+        hipLaunchKernelGGL(k_nyquist_reduce, dim3(2 * 2 * EDGE_MAX / NYQ_RED_IDX), dim3(256), 0, st, w.gam, chunks);
         hipLaunchKernelGGL(k_nyquist_profiles, dim3((pn + 255) / 256, 2), dim3(256), 0, st, w.gam, w.twtab, eg, N);
         hipLaunchKernelGGL(k_nyquist_apply, dim3((pn + 255) / 256, pn), dim3(256), 0, st, out, w.gam, pn);
         HIP_TRY(hipGetLastError());
@@ -875,10 +889,11 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     AbbePlan pc_plan;
     const SizeOps* ops_c = nullptr;
     EdgeGeom eg;
-    // The reconstruction is a fixed cost per call and plane (about ten small launches: 0.3 ms at 256^2 .. 1.5 ms at
-    // 4096^2), so short source lists stay on the direct path: break-even measured at S = 14,000 (256^2), 1,200
-    // (512^2), < 500 (1024^2), about 100 (2048^2, 4096^2); scripts/total_time.py.  LITHO_ABBE_COARSE = 2 ignores S.
-    const int64_t s_min = pn == 256 ? 16384 : pn == 512 ? 1536 : pn == 1024 ? 384 : 128;
+    // The reconstruction is a fixed cost per call and plane (about ten small launches: 0.08 ms at 256^2 .. 0.5 ms at 4096^2
+    // since round 4, when k_nyquist_reduce stopped taking 0.27 ms by itself), so short source lists stay on the direct path.
+    // Break-even measured (scripts/coarse_breakeven.py, whole-call time, profiles/r04_coarse_breakeven.txt): S = 2,900 (256^2),
+    // 400 (512^2), 180 (1024^2), 64 (2048^2), 48 (4096^2); thresholds a notch above.  LITHO_ABBE_COARSE = 2 ignores S.
+    const int64_t s_min = pn == 256 ? 3072 : pn == 512 ? 512 : pn == 1024 ? 256 : pn == 2048 ? 96 : 64;
     bool coarse = kn.coarse && (kn.coarse >= 2 || S >= s_min) && coarse_eligible(pn, N) && pp.variant == 1 && pp.natural_box &&
                   pl[13] == 0;
     if (coarse) {

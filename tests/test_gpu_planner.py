@@ -195,7 +195,7 @@ def test_support_box_one_sample_inside_and_outside_the_natural_box(L, dev, pn, s
 
 
 # ------------------------------------------------------------------ source-count threshold of the default mode
-@pytest.mark.parametrize("pn,s_min", [(512, 1536), (1024, 384)])
+@pytest.mark.parametrize("pn,s_min", [(512, 512), (1024, 256), (2048, 96)])
 def test_source_count_threshold_of_the_coarse_grid(L, dev, pn, s_min):
     """Default mode (coarse = 1): S = s_min - 1 stays on the direct path, S = s_min takes the coarse grid; both are the
     reference's image (the oracle's op chain over the same consecutive points)."""

@@ -14,7 +14,8 @@ src = os.path.join(ROOT, "gpurun_out", R)
 dst = os.path.join(ROOT, "profiles")
 pairs = [("bench.json", f"{R}_bench.json"), ("bench_under_rocprof.json", f"{R}_bench_under_rocprof.json"),
          ("stats/bench_kernel_stats.csv", f"{R}_bench_kernel_stats.csv"), ("bench_cfg1.json", f"{R}_bench_cfg1.json"),
-         ("bench_cfg2.json", f"{R}_bench_cfg2.json"), ("bench_cfg4_shard0of8.json", f"{R}_bench_cfg4_shard0of8.json")]
+         ("bench_cfg2.json", f"{R}_bench_cfg2.json"), ("bench_cfg4_shard0of8.json", f"{R}_bench_cfg4_shard0of8.json"),
+         ("bench_cfg3_shard0of8.json", f"{R}_bench_cfg3_shard0of8.json"), ("bench_cfg5_shard0of8.json", f"{R}_bench_cfg5_shard0of8.json")]
 pairs += [(os.path.basename(p), f"{R}_" + os.path.basename(p)) for p in glob.glob(os.path.join(src, "pmc_cfg*_summary.txt"))]
 for a, b in pairs:
     pa = os.path.join(src, a)

@@ -108,9 +108,12 @@ def test_demo_image_vs_golden(golden, L, dev):
     assert rel_max(raw, g["demo64_raw"]) < TOL_IMAGE_MAX and rel_l2(raw, g["demo64_raw"]) < TOL_IMAGE_L2
 
 
+@pytest.mark.parametrize("path", ["default", "direct"])
 @pytest.mark.parametrize("kind", ["bern", "lines"])
-def test_config1_vs_golden(golden, L, dev, kind):
-    """BASELINE config 1 (256^2, circular sigma 0.5, ideal pupil, S = 3233), end to end."""
+def test_config1_vs_golden(golden, L, dev, kind, path):
+    """BASELINE config 1 (256^2, circular sigma 0.5, ideal pupil, S = 3233), end to end: as a caller gets it (since round 4
+    the coarse grid: 3233 points are past its 3072-point break-even at 256^2) and on the direct path."""
+    from lithographysimulator_amd import _native as nat
     from lithographysimulator_amd.synthetic import bernoulli_mask, lines_mask
     g = golden("g5_images.npz")
     geo = bernoulli_mask(256) if kind == "bern" else lines_mask(256)
@@ -118,7 +121,8 @@ def test_config1_vs_golden(golden, L, dev, kind):
     mft = mask.fraunhofer(WL, True)
     bm = L.LightSource(0.0, 0.5, 256, NA, device=dev).generateAnnular()
     pf = L.Pupil(256, WL, NA, None, dev).generatePupilFunction()
-    img = L.abbeImage(mask, mft, pf, bm, PS, mask.deltaK, WL, True, dev).cpu()
+    img = L.abbeImage(mask, mft, pf, bm, PS, mask.deltaK, WL, True, dev, options=None if path == "default" else {"coarse": 0}).cpu()
+    assert nat.last_plan()["coarse_grid"] == (1 if path == "default" else 0), nat.last_plan()
     assert rel_max(img, g[f"cfg1_{kind}_final"]) < TOL_IMAGE_MAX
     assert rel_l2(img, g[f"cfg1_{kind}_final"]) < TOL_IMAGE_L2
 
@@ -633,11 +637,12 @@ def test_poisoned_scratch_changes_nothing(L, dev, monkeypatch, pn, mode):
     assert bool(torch.isfinite(dirty).all()) and torch.equal(clean, dirty)
 
 
-@pytest.mark.parametrize("pn", [256, 512])
-def test_planned_call_is_capturable_in_a_hip_graph(L, dev, pn):
+@pytest.mark.parametrize("pn,coarse", [(256, 0), (256, 1), (512, 1)])
+def test_planned_call_is_capturable_in_a_hip_graph(L, dev, pn, coarse):
     """With a valid PlanCache the accumulate call launches no planning kernel and never waits for the stream, so the
     whole abbeImage call can be captured into ONE HIP graph (torch.cuda.CUDAGraph) and replayed for mask after mask:
-    the replay gives the eager image bit for bit, also after the mask spectrum in the static input buffer changed."""
+    the replay gives the eager image bit for bit, also after the mask spectrum in the static input buffer changed.
+    Both evaluation paths: the direct one (options coarse = 0) and the planner's own choice (coarse grid at these S)."""
     from lithographysimulator_amd import _native as nat
     from lithographysimulator_amd.synthetic import bernoulli_mask, lines_mask
     bm = L.LightSource(0.0, 0.5, pn, NA, device=dev).generateAnnular()
@@ -645,18 +650,18 @@ def test_planned_call_is_capturable_in_a_hip_graph(L, dev, pn):
     m1, m2 = L.Mask(bernoulli_mask(pn), PS, dev), L.Mask(lines_mask(pn), PS, dev)
     f1, f2 = m1.fraunhofer(WL, True), m2.fraunhofer(WL, True)
     cache = L.PlanCache()
-    e1 = L.abbeImage(m1, f1, pf, bm, PS, m1.deltaK, WL, True, dev, plan_cache=cache)
-    e2 = L.abbeImage(m2, f2, pf, bm, PS, m2.deltaK, WL, True, dev, plan_cache=cache)
-    assert cache.valid and nat.last_plan()["coarse_grid"] == (1 if pn == 512 else 0)      # both evaluation paths
+    e1 = L.abbeImage(m1, f1, pf, bm, PS, m1.deltaK, WL, True, dev, plan_cache=cache, options={"coarse": coarse})
+    e2 = L.abbeImage(m2, f2, pf, bm, PS, m2.deltaK, WL, True, dev, plan_cache=cache, options={"coarse": coarse})
+    assert cache.valid and nat.last_plan()["coarse_grid"] == coarse
     static = f1.clone()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        L.abbeImage(m1, static, pf, bm, PS, m1.deltaK, WL, True, dev, plan_cache=cache)
+        L.abbeImage(m1, static, pf, bm, PS, m1.deltaK, WL, True, dev, plan_cache=cache, options={"coarse": coarse})
     torch.cuda.current_stream().wait_stream(side)
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
-        out = L.abbeImage(m1, static, pf, bm, PS, m1.deltaK, WL, True, dev, plan_cache=cache)
+        out = L.abbeImage(m1, static, pf, bm, PS, m1.deltaK, WL, True, dev, plan_cache=cache, options={"coarse": coarse})
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, e1)

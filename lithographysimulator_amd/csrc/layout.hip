@@ -24,7 +24,9 @@ __global__ __launch_bounds__(256) void k_raster_edges(const double* __restrict__
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= ne) return;
     const double x0 = edges[4 * e], y0 = edges[4 * e + 1], x1 = edges[4 * e + 2], y1 = edges[4 * e + 3];
-    if (!(y0 == y0 && y1 == y1 && x0 == x0 && x1 == x1) || y0 == y1) return;      // NaN or horizontal: no crossing
+    // a non-finite coordinate (NaN or +-inf: inf * 0 and inf - inf below would be NaN and the cast to int undefined) or a
+    // horizontal edge: no crossing
+    if (!(isfinite(x0) && isfinite(y0) && isfinite(x1) && isfinite(y1)) || y0 == y1) return;
     const int dir = y1 > y0 ? 1 : -1;
     const double ymin = y0 < y1 ? y0 : y1, ymax = y0 < y1 ? y1 : y0;
     // candidate rows: one spare on both sides, the exact test below decides

@@ -248,9 +248,14 @@ def writeGDSII(lib: GdsLibrary, path: Optional[str] = None) -> bytes:
     return blob
 
 
+MITRE_LIMIT = 2.0          # mitre length / half-width beyond which a path joint is bevelled
+
+
 def pathOutline(xy: np.ndarray, width: float, pathtype: int = 0, bgnextn: float = 0.0, endextn: float = 0.0) -> np.ndarray:
     """Outline polygon of a PATH: the centre line offset by width / 2 on both sides, mitred joints.  Path type 0:
-    flush ends, 2: ends extended by width / 2, 4: by BGNEXTN / ENDEXTN, 1 (round ends) is drawn as type 2."""
+    flush ends, 2: ends extended by width / 2, 4: by BGNEXTN / ENDEXTN, 1 (round ends) is drawn as type 2.  Joints sharper
+    than MITRE_LIMIT allows are bevelled.  Only SIMPLE outlines rasterise as drawn: a path that crosses itself, or whose
+    inner corner folds over on a segment shorter than its width, still unions by summed winding numbers."""
     p = np.asarray(xy, dtype=np.float64)
     keep = np.ones(len(p), dtype=bool)
     keep[1:] = np.any(p[1:] != p[:-1], axis=1)                 # repeated points have no direction
@@ -268,16 +273,33 @@ def pathOutline(xy: np.ndarray, width: float, pathtype: int = 0, bgnextn: float 
     left, right = [], []
     for i in range(len(p)):
         if i == 0:
-            off = nrm[0] * hw
-        elif i == len(p) - 1:
-            off = nrm[-1] * hw
+            left.append(p[0] + nrm[0] * hw); right.append(p[0] - nrm[0] * hw)
+            continue
+        if i == len(p) - 1:
+            left.append(p[-1] + nrm[-1] * hw); right.append(p[-1] - nrm[-1] * hw)
+            continue
+        # mitre: the point at distance hw from both segments' centre lines, b * hw / (1 + n0.n1), length hw / cos(half turn).
+        # Beyond MITRE_LIMIT * hw (a turn sharper than ~120 degrees) the joint is BEVELLED like layout tools do: the two
+        # segment offsets themselves, so an acute or nearly reversing joint cannot throw a spike of 1e4 half-widths (and
+        # a self-intersecting outline whose negative lobes would cancel neighbouring polygons in the summed-winding raster).
+        b = nrm[i - 1] + nrm[i]
+        den = 1.0 + float(np.dot(nrm[i - 1], nrm[i]))
+        if den > 1e-9 and float(np.linalg.norm(b)) / den <= MITRE_LIMIT:
+            left.append(p[i] + b * (hw / den)); right.append(p[i] - b * (hw / den))
         else:
-            # mitre: the point at distance hw from both segments' centre lines
-            b = nrm[i - 1] + nrm[i]
-            den = 1.0 + float(np.dot(nrm[i - 1], nrm[i]))
-            off = b * (hw / den) if den > 1e-9 else nrm[i] * hw   # a 180-degree reversal has no mitre
-        left.append(p[i] + off)
-        right.append(p[i] - off)
+            turn_left = float(d[i - 1][0] * d[i][1] - d[i - 1][1] * d[i][0]) > 0.0
+            # outer side of the turn gets the two bevel corners; the inner side keeps the (clamped) mitre point
+            inner = b * (hw / den) if den > 1e-9 else nrm[i] * 0.0
+            lim = MITRE_LIMIT * hw
+            ln = float(np.linalg.norm(inner))
+            if ln > lim:
+                inner = inner * (lim / ln)
+            if turn_left:                                      # outer side = right
+                left.append(p[i] + inner)
+                right.append(p[i] - nrm[i - 1] * hw); right.append(p[i] - nrm[i] * hw)
+            else:                                              # outer side = left
+                left.append(p[i] + nrm[i - 1] * hw); left.append(p[i] + nrm[i] * hw)
+                right.append(p[i] - inner)
     return np.array(left + right[::-1])
 
 

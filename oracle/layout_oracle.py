@@ -34,7 +34,8 @@ def rasterize_edges(edges: np.ndarray, pn: int, x0: float, y0: float, pixel: flo
 
 
 def point_in_polygons(polygons, x: float, y: float) -> bool:
-    """Independent check for single points: non-zero winding by the classical crossing count."""
+    """Independent check for single points: non-zero SUMMED winding number over all polygons by the classical crossing
+    count -- the kernel's definition (a clockwise lobe cancels an overlapping counter-clockwise polygon)."""
     total = 0
     for q in polygons:
         q = np.asarray(q, dtype=np.float64)
@@ -44,5 +45,5 @@ def point_in_polygons(polygons, x: float, y: float) -> bool:
                 w += 1
             elif yb <= y < ya and (xa + (y - ya) * (xb - xa) / (yb - ya)) > x:
                 w -= 1
-        total += abs(w)
+        total += w
     return total != 0

@@ -113,6 +113,26 @@ def test_path_outline_shapes():
     d = LY.pathOutline(np.array([[0, 0], [100, 100]]), 2 * np.sqrt(2.0), 0)  # a diagonal wire of half-width sqrt 2
     assert sorted(map(tuple, d.round(9))) == sorted([(-1, 1), (1, -1), (99, 101), (101, 99)])
     assert len(LY.pathOutline(np.array([[5, 5], [5, 5]]), 10, 0)) == 0       # no direction, no outline
+    # acute and nearly reversing joints are bevelled: the outline stays within MITRE_LIMIT half-widths of the centre line
+    # (an unbounded mitre used to throw spikes of 1e4 half-widths there), and it stays a simple counter-clockwise loop
+    for tip in (20.0, 1.0, 1e-3):
+        q = LY.pathOutline(np.array([[0, 0], [100, 0], [0, tip]]), 20, 0)
+        assert len(q) == 7 and q[:, 0].max() <= 100 + LY.MITRE_LIMIT * 10 + 1e-9 and q[:, 0].min() >= -10 - 1e-9
+        assert np.abs(q[:, 1]).max() <= max(tip, 0) + LY.MITRE_LIMIT * 10 + 1e-9
+    assert len(LY.pathOutline(np.array([[0, 0], [100, 0], [100, 100], [0, 100]]), 20, 0)) == 8      # right angles keep the mitre
+
+
+def test_restatement_skips_non_finite_edges():
+    """NaN and +-inf coordinates contribute nothing (the kernel tests isfinite on all four, as this restatement does)."""
+    from oracle import layout_oracle as LO
+    good = LY.polygonEdges([rect(2, 1, 7, 4)])
+    bad = np.array([[np.inf, 0.0, 3.0, 5.0], [1.0, -np.inf, 1.0, 4.0], [np.nan, 0.0, 2.0, 9.0], [0.0, 0.0, -np.inf, 8.0]])
+    assert np.array_equal(LO.rasterize_edges(np.concatenate([good, bad]), 8, 0.0, 0.0, 1.0), LO.rasterize_edges(good, 8, 0.0, 0.0, 1.0))
+    # summed winding: a clockwise copy cancels a counter-clockwise polygon (the kernel's union rule), and the point test agrees
+    ccw = rect(1, 1, 5, 5)
+    assert LO.point_in_polygons([ccw], 2.5, 2.5) and not LO.point_in_polygons([ccw, ccw[::-1]], 2.5, 2.5)
+    e = LY.polygonEdges([ccw])                                   # (polygonEdges orients its input: reverse the edges by hand)
+    assert int(LO.rasterize_edges(np.concatenate([e, e[:, [2, 3, 0, 1]]]), 8, 0.0, 0.0, 1.0).sum()) == 0
 
 
 def test_raster_restatement_closed_forms():

@@ -30,7 +30,7 @@ def per_class(counter, sub):
             # per-source-point kernels only (the once-per-image reconstruction transforms are not T-item work)
             cls = ("xpass" if any(k in name for k in ("k_xpass_abbe", "k_xpass_split", "k_xpass_rect", "k_xpass_w64"))
                    else "ypass" if any(k in name for k in ("k_ypass_wave", "k_ypass_rect", "k_ypass_pair",
-                                                           "k_ypass_acc", "k_ypass_w64")) else None)
+                                                           "k_ypass_acc", "k_ypass_w64", "k_ypass_coop")) else None)
             if cls:
                 tot[cls] += float(row["Counter_Value"])
                 n[cls] += 1

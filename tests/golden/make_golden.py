@@ -489,6 +489,38 @@ def g13_config3_long_run():
     save("g13_config3_long_run.npz", **out)
 
 
+def g14_config3_rank_shard():
+    """ONE RANK'S SHARD of BASELINE config 3 at 8 GPUs, in full, by the reference itself: source points [0, 24764) of the
+    2048^2 quasar list (distributed.shard_bounds(198108, 0, 8)) through the reference's own abbeImage -- its sequential fp32
+    sum of 24,764 images (about an hour and a half of this container's CPUs).  The engine runs this as 2,064 of its default
+    12-point batches with 32 slab folds: the per-rank work of the 8-GPU run, on dense reference-made data."""
+    print("G14 config 3, rank 0 of 8: 24,764 consecutive points at 2048^2")
+    import time
+    pn, lo, n = 2048, 0, 24764
+    out = {}
+    mk = quiet(ref_mask.Mask, bernoulli_mask(pn), PS, CPU)
+    mft = mk.fraunhofer(WL, True)
+    full = source("quasar", pn, 0.4, 0.8)
+    pts = torch.argwhere(full)
+    assert pts.shape[0] == 198108
+    bm = torch.zeros_like(full)
+    sel = pts[lo:lo + n]
+    bm[sel[:, 0], sel[:, 1]] = 1
+    pf = pupil_fn(pn, DEMO_AB)
+    t0 = time.time()
+    final, raw = full_image_with_raw(mk, mft, pf, bm)
+    out["reference_seconds"] = np.float64(time.time() - t0)
+    out["reference_threads"] = np.int64(torch.get_num_threads())
+    for tag, img in (("final", final), ("raw", raw)):
+        crop_stats(f"cfg3shard_{tag}", img, out)
+        out[f"cfg3shard_{tag}_stride16"] = img[::16, ::16].contiguous()
+    out["cfg3shard_range"] = np.array([lo, lo + n, pts.shape[0]], dtype=np.int64)
+    out["cfg3shard_first_last_shift"] = shifts_of(bm, pn)[[0, -1]]
+    print(f"   points [{lo},{lo + n}) of {pts.shape[0]}  {float(out['reference_seconds']):.0f} s  final sum "
+          f"{float(final.double().sum()):.7e}", flush=True)
+    save("g14_config3_rank_shard.npz", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     if os.environ.get("LITHO_GOLDEN_THREADS"):
@@ -497,4 +529,4 @@ if __name__ == "__main__":
     for g in which:
         {"g1": g1_sources, "g2": g2_pupils, "g3": g3_mask_spectra, "g4": g4_fields,
          "g5": g5_images, "g6": g6_through_focus, "g8": g8_large_pupils, "g9": g9_config5_stack, "g10": g10_contiguous_shards,
-         "g11": g11_config2_full, "g12": g12_shard4096, "g13": g13_config3_long_run}[g]()
+         "g11": g11_config2_full, "g12": g12_shard4096, "g13": g13_config3_long_run, "g14": g14_config3_rank_shard}[g]()

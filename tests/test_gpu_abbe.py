@@ -33,13 +33,22 @@ def O():
     return abbe_oracle
 
 
+def _opt(monkeypatch, **kw):
+    """Launch-planner options for the REST of this test: pushed onto this thread's engineOptions stack (they travel through
+    litho_abbe_options with every Abbe call; monkeypatch restores the stack at teardown).  Not the environment."""
+    from lithographysimulator_amd import _native as nat
+    kw = {k: int(v) for k, v in kw.items()}
+    nat.Options.make(kw)                                   # validates the names
+    monkeypatch.setattr(nat._option_stack, "v", list(getattr(nat._option_stack, "v", None) or []) + [kw], raising=False)
+
+
 @pytest.fixture(params=["auto", "coarse"])
 def coarse_mode(request, monkeypatch):
     """The library picks the coarse-grid path only for source lists long enough to repay its once-per-image
     reconstruction; the golden-vector tests at the BASELINE sizes use a handful of points, so they run twice: as a
     caller gets it ("auto": the direct path here) and with the coarse-grid path forced (LITHO_ABBE_COARSE=2)."""
     if request.param == "coarse":
-        monkeypatch.setenv("LITHO_ABBE_COARSE", "2")
+        _opt(monkeypatch, coarse="2")
     return request.param
 
 
@@ -210,7 +219,7 @@ def test_general_and_pruned_modes_agree(golden, L, dev, monkeypatch):
     N = int(g["bern256_N"])
     shifts = torch.tensor([[0, 0], [51, -51], [-40, 13], [10, 3]], dtype=torch.int32)
     a = _raw(L, dev, mft, pf, shifts, N).cpu()
-    monkeypatch.setenv("LITHO_ABBE_FORCE_GENERAL", "1")
+    _opt(monkeypatch, force_general="1")
     b = _raw(L, dev, mft, pf, shifts, N).cpu()
     assert rel_max(a, b) < 5e-6
 
@@ -280,7 +289,7 @@ def test_coarse_grid_path_agrees_with_direct_path(L, dev, monkeypatch, pn, ab):
     an accumulate-into-live-buffer call; ideal pupil (real, box edges at their smallest) and a 15-term pupil."""
     from lithographysimulator_amd import _native as nat
     from lithographysimulator_amd.synthetic import bernoulli_mask
-    monkeypatch.setenv("LITHO_ABBE_COARSE", "2")                 # short source lists: force the path under test
+    _opt(monkeypatch, coarse="2")                 # short source lists: force the path under test
     mask = L.Mask(bernoulli_mask(pn), PS, dev)
     mft = mask.fraunhofer(WL, True)
     eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
@@ -315,7 +324,7 @@ def test_coarse_grid_xpass_kernels_agree(L, dev, monkeypatch, pn):
     stores): both must give the same image, ragged last row group and several batches included."""
     from lithographysimulator_amd import _native as nat
     from lithographysimulator_amd.synthetic import bernoulli_mask
-    monkeypatch.setenv("LITHO_ABBE_COARSE", "2")
+    _opt(monkeypatch, coarse="2")
     mask = L.Mask(bernoulli_mask(pn), PS, dev)
     mft = mask.fraunhofer(WL, True)
     eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
@@ -401,20 +410,15 @@ def test_config5_stack_at_size_vs_golden(golden, L, dev, coarse_mode):
     part = L.abbeIntensity(mft, stack[4:11], shifts, N).cpu()
     for j in range(7):
         assert rel_max(part[j], raw[4 + j]) < 1e-6, j
-    import os
     for pc in ("4", "2"):
-        os.environ["LITHO_ABBE_PLANE_CHUNK"] = pc
-        try:
-            fused = L.abbeIntensity(mft, stack[8:15], shifts, N).cpu()
-            assert nat.last_plan()["planes_in_flight"] == int(pc)
-        finally:
-            del os.environ["LITHO_ABBE_PLANE_CHUNK"]
+        fused = L.abbeIntensity(mft, stack[8:15], shifts, N, options={"plane_chunk": int(pc)}).cpu()
+        assert nat.last_plan()["planes_in_flight"] == int(pc)
         for j in range(7):
             assert rel_max(fused[j], raw[8 + j]) < 1e-6, (pc, j)
 
 
 def test_stack_plane_chunk_knob_and_generic_variant(L, dev, monkeypatch):
-    monkeypatch.setenv("LITHO_ABBE_COARSE", "0")          # this test is about the kernels of the DIRECT (N = 2 pn) path
+    _opt(monkeypatch, coarse="0")          # this test is about the kernels of the DIRECT (N = 2 pn) path
     _test_stack_plane_chunk_knob_and_generic_variant(L, dev, monkeypatch)
 
 
@@ -457,7 +461,7 @@ def test_contiguous_shard_vs_golden(golden, L, dev, monkeypatch, tag, pn, skind,
     from lithographysimulator_amd import _native as nat
     from lithographysimulator_amd.synthetic import bernoulli_mask
     if path == "direct":
-        monkeypatch.setenv("LITHO_ABBE_COARSE", "0")
+        _opt(monkeypatch, coarse="0")
     g = golden("g10_contiguous_shards.npz")
     lo, hi, S = (int(v) for v in g[f"{tag}_range"])
     mask = L.Mask(bernoulli_mask(pn), PS, dev)
@@ -533,12 +537,12 @@ def test_consecutive_shard_4096_vs_golden(golden, L, dev, monkeypatch, path):
     from lithographysimulator_amd.synthetic import bernoulli_mask
     g = golden("g12_shard4096.npz")
     pn = 4096
-    monkeypatch.setenv("LITHO_ABBE_COARSE", "2" if path.startswith("coarse") else "0")
+    _opt(monkeypatch, coarse="2" if path.startswith("coarse") else "0")
     default_batch = path.endswith("default-batch")
     if not default_batch:
-        monkeypatch.setenv("LITHO_ABBE_BATCH", "12")           # 64 points = 5 full batches + a ragged one (the default batch is 60 here)
-    if "tile8" in path: monkeypatch.setenv("LITHO_ABBE_TILE", "8")
-    if "rowpairs" in path: monkeypatch.setenv("LITHO_ABBE_ROWPAIRS", "1")
+        _opt(monkeypatch, batch="12")           # 64 points = 5 full batches + a ragged one (the default batch is 60 here)
+    if "tile8" in path: _opt(monkeypatch, tile="8")
+    if "rowpairs" in path: _opt(monkeypatch, rowpairs="1")
     lo, hi, S = (int(v) for v in g["cfg4shard_range"])
     mask = L.Mask(bernoulli_mask(pn), PS, dev)
     mft = mask.fraunhofer(WL, True)
@@ -773,7 +777,7 @@ def test_config2_full_source_vs_reference_golden(golden, L, dev, monkeypatch, pa
     g = golden("g11_config2_full.npz")
     pn = 1024
     if path == "direct":
-        monkeypatch.setenv("LITHO_ABBE_COARSE", "0")
+        _opt(monkeypatch, coarse="0")
     mask = L.Mask(bernoulli_mask(pn), PS, dev)
     mft = mask.fraunhofer(WL, True)
     eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
@@ -837,7 +841,7 @@ def test_few_beam_spectrum_closed_form_full_source(L, dev, monkeypatch, pn, skin
     three-beam interference fringes whose offset and complex contrasts are plain float64 sums over the source list.  First
     pinned against the oracle's op chain on a small case, then every pixel of the GPU image is compared with it."""
     from lithographysimulator_amd import _native as nat
-    monkeypatch.setenv("LITHO_ABBE_COARSE", "2" if path == "coarse" else "0")
+    _opt(monkeypatch, coarse="2" if path == "coarse" else "0")
 
     amps = [1.0 + 0.5j, -0.75 + 0.25j, 0.3 - 1.1j]
     # the formula against the oracle's op chain, small: 64^2, N = 128, 40 source points
@@ -1000,11 +1004,7 @@ def test_properties_2048(L, dev):
     parts = L.abbeIntensity(mft, pf, sel[:13], N)
     L.abbeIntensity(mft, pf, sel[13:], N, out=parts)                 # accumulate into a live buffer
     assert rel_max(parts.cpu(), whole.cpu()) < 2e-6
-    os.environ["LITHO_ABBE_BATCH"] = "7"
-    try:
-        rebatched = L.abbeIntensity(mft, pf, sel, N)
-    finally:
-        del os.environ["LITHO_ABBE_BATCH"]
+    rebatched = L.abbeIntensity(mft, pf, sel, N, options={"batch": 7})
     assert rel_max(rebatched.cpu(), whole.cpu()) < 2e-6
     scaled = L.abbeIntensity(mft * (0.5 + 0.25j), pf, sel, N)
     assert rel_max(scaled.cpu(), whole.cpu() * abs(0.5 + 0.25j) ** 2) < 2e-6
@@ -1019,22 +1019,15 @@ def test_properties_2048(L, dev):
 
 # ------------------------------------------------------------------ kernel variants must agree with each other
 def _with_env(monkeypatch, L, env, fn):
-    import os
-    old = {k: os.environ.get(k) for k in env}
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    try:
+    """Run fn() under the launch-planner options named by `env` ({"LITHO_ABBE_COARSE": "2", ...}: the historical spelling
+    of the knobs), passed PER CALL through litho_abbe_options (engineOptions) -- the process environment is not touched."""
+    from lithographysimulator_amd import _native as nat
+    with nat.engineOptions(**{k[len("LITHO_ABBE_"):].lower(): int(v) for k, v in env.items()}):
         return fn()
-    finally:
-        for k, v in old.items():
-            if v is None:
-                monkeypatch.delenv(k, raising=False)
-            else:
-                monkeypatch.setenv(k, v)
 
 
 def test_wave_per_line_and_radix16_ypass_agree_2048(L, dev, monkeypatch):
-    monkeypatch.setenv("LITHO_ABBE_COARSE", "0")          # this test is about the kernels of the DIRECT (N = 2 pn) path
+    _opt(monkeypatch, coarse="0")          # this test is about the kernels of the DIRECT (N = 2 pn) path
     _test_wave_per_line_and_radix16_ypass_agree_2048(L, dev, monkeypatch)
 
 
@@ -1071,7 +1064,7 @@ def _test_wave_per_line_and_radix16_ypass_agree_2048(L, dev, monkeypatch):
 
 
 def test_2048_kernels_agree_1024(L, dev, monkeypatch):
-    monkeypatch.setenv("LITHO_ABBE_COARSE", "0")          # this test is about the kernels of the DIRECT (N = 2 pn) path
+    _opt(monkeypatch, coarse="0")          # this test is about the kernels of the DIRECT (N = 2 pn) path
     _test_2048_kernels_agree_1024(L, dev, monkeypatch)
 
 
@@ -1109,7 +1102,7 @@ def _test_2048_kernels_agree_1024(L, dev, monkeypatch):
 
 @pytest.mark.parametrize("pn", [256, 512])
 def test_small_size_kernels_agree(L, dev, monkeypatch, pn):
-    monkeypatch.setenv("LITHO_ABBE_COARSE", "0")          # this test is about the kernels of the DIRECT (N = 2 pn) path
+    _opt(monkeypatch, coarse="0")          # this test is about the kernels of the DIRECT (N = 2 pn) path
     _test_small_size_kernels_agree(L, dev, monkeypatch, pn)
 
 
@@ -1142,7 +1135,7 @@ def _test_small_size_kernels_agree(L, dev, monkeypatch, pn):
 
 
 def test_8192_kernels_agree_4096(L, dev, monkeypatch):
-    monkeypatch.setenv("LITHO_ABBE_COARSE", "0")          # this test is about the kernels of the DIRECT (N = 2 pn) path
+    _opt(monkeypatch, coarse="0")          # this test is about the kernels of the DIRECT (N = 2 pn) path
     _test_8192_kernels_agree_4096(L, dev, monkeypatch)
 
 
@@ -1187,7 +1180,7 @@ def test_coarse_grid_4096_tile_layouts_agree(L, dev, monkeypatch):
     from lithographysimulator_amd.synthetic import bernoulli_mask
     pn = 4096
     c = pn // 2
-    monkeypatch.setenv("LITHO_ABBE_COARSE", "2")
+    _opt(monkeypatch, coarse="2")
     mask = L.Mask(bernoulli_mask(pn), PS, dev)
     mft = mask.fraunhofer(WL, True)
     eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)

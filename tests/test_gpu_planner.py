@@ -242,6 +242,30 @@ def test_shift_one_sample_short_of_wrapping_and_one_past(L, dev, pn, axis, sign)
             _check(got, ref, f"{pn}^2 shift {big} on axis {axis} (wraps: {past}), coarse={coarse}")
 
 
+def test_environment_variables_remain_a_fallback_and_options_win(L, dev, monkeypatch):
+    """Options passed per call beat the LITHO_ABBE_* variables; a field the caller leaves unset falls back to the variable,
+    then to the default."""
+    pn, N = 512, 1024
+    mft = _mask_spectrum(L, dev, pn)
+    pupil = _disk(L, dev, pn)
+    sel = _strided_points(L, dev, pn, 600)
+    base = L.abbeIntensity(mft, pupil, sel, N)
+    assert nat().last_plan()["coarse_grid"] == 1                       # default rule: 600 points >= 512
+    monkeypatch.setenv("LITHO_ABBE_COARSE", "0")
+    monkeypatch.setenv("LITHO_ABBE_BATCH", "7")
+    env_only = L.abbeIntensity(mft, pupil, sel, N)
+    plan = nat().last_plan()
+    assert plan["coarse_grid"] == 0 and plan["batch"] == 7, plan
+    both = L.abbeIntensity(mft, pupil, sel, N, options={"coarse": 2})
+    plan = nat().last_plan()
+    assert plan["coarse_grid"] == 1 and plan["batch"] == 7, plan       # `coarse` from the call, `batch` still from the variable
+    with nat().engineOptions(batch=9):
+        L.abbeIntensity(mft, pupil, sel, N)
+        plan = nat().last_plan()
+        assert plan["coarse_grid"] == 0 and plan["batch"] == 9, plan
+    assert rel_max(env_only.cpu(), base.cpu()) < 2e-6 and rel_max(both.cpu(), base.cpu()) < 2e-6
+
+
 # ------------------------------------------------------------------ seeded fuzz
 FUZZ_CASES = 320
 

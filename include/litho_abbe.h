@@ -34,6 +34,7 @@ extern "C" {
 #define LITHO_E_WORKSPACE (-3)  /* workspace too small                                        */
 #define LITHO_E_HIP (-4)        /* a HIP runtime call failed; see litho_last_error()           */
 #define LITHO_E_INDEX (-5)      /* aberration vector of length 4 (pupil.py:91-92)   */
+#define LITHO_E_WRAP (-6)       /* options.embed_pn: a shifted pupil support leaves the ORIGINAL grid (nothing was launched) */
 
 /* Library version and the gfx target it was compiled for ("gfx950"). */
 int litho_version(void);
@@ -140,6 +141,11 @@ typedef struct litho_abbe_options {
     int32_t w64, rect, w64_8192, xsplit, xrect, w64x, gcombine, rowpairs;   /* kernel families, DESIGN.md section 8 */
     int32_t force_generic, force_general;                                  /* runtime-predicated kernels / modular gather */
     int32_t poison;          /* 1: scratch starts the call as NaN bit patterns (tests) */
+    int32_t embed_pn;        /* > 0: maskFT / pupil are a grid of THIS size embedded, centred and zero-padded, in the pn x pn
+                              * arrays of the call (how the host side runs mask sizes other than N and N/2 on the power-of-two
+                              * kernels: pad, call, crop the image).  The call returns LITHO_E_WRAP, having accumulated nothing, if
+                              * a shift would wrap the pupil around the original grid (the reference rolls modulo ITS size,
+                              * imageformation.py:63): the caller then calls with its own size. */
 } litho_abbe_options;
 int litho_abbe_accumulate_opts(const void *maskFT, const void *pupil, int planes, const int32_t *shifts,
                                const int32_t *count_dev, int64_t capacity, int pn, int N, float *out,

@@ -1,7 +1,7 @@
 """MI355X-native Abbe aerial-image engine behind the object API of
 quarterwave0/LithographySimulator (Mask / LightSource / Pupil / abbeImage)."""
 from .imageformation import (PlanCache, abbeImage, abbeIntensity, bossungCurves, calculateFFTAerial,   # noqa: F401
-                             postProcess, resistContour)
+                             embeddedSize, postProcess, resistContour)
 from ._native import engineOptions                                                      # noqa: F401
 from .layout import (GdsLibrary, flattenLayout, maskFromGDSII, rasterizeLayout, readGDSII,  # noqa: F401
                      writeGDSII)
@@ -10,6 +10,6 @@ from .mask import Mask                                                          
 from .pupil import (OSAindexToMN, Pupil, generatePhi, generateWavefrontError,           # noqa: F401
                     generateZ, throughFocusPupils)
 
-__all__ = ["Mask", "LightSource", "Pupil", "abbeImage", "abbeIntensity", "calculateFFTAerial", "postProcess", "resistContour", "bossungCurves", "PlanCache", "engineOptions",
+__all__ = ["Mask", "LightSource", "Pupil", "abbeImage", "abbeIntensity", "calculateFFTAerial", "postProcess", "resistContour", "bossungCurves", "PlanCache", "engineOptions", "embeddedSize",
            "sourceShifts", "sourceShiftsAsync", "OSAindexToMN", "generateWavefrontError", "generatePhi", "generateZ",
            "throughFocusPupils", "readGDSII", "writeGDSII", "flattenLayout", "rasterizeLayout", "maskFromGDSII", "GdsLibrary"]

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LITHO_ABBE_LIB") or os.path.join(_HERE, "lib", "liblitho_abbe.so")
 
-LITHO_OK, E_ARG, E_NSMALL, E_WORKSPACE, E_HIP, E_INDEX = 0, -1, -2, -3, -4, -5
+LITHO_OK, E_ARG, E_NSMALL, E_WORKSPACE, E_HIP, E_INDEX, E_WRAP = 0, -1, -2, -3, -4, -5, -6
 _lib = None
 
 _SIGNATURES = {
@@ -123,6 +123,7 @@ def ptr(t):
     return c_void_p(t.data_ptr())
 
 
+EMBED_ODD_SIZES = True       # abbeIntensity runs mask sizes other than N and N/2 embedded in the next such grid (imageformation.embeddedSize)
 _workspaces = {}
 WORKSPACE_CACHE_BYTES = 8 << 30      # the cache keeps at most this much per device (one entry always stays)
 
@@ -168,7 +169,7 @@ class PlanRecord(ctypes.Structure):
 class Options(ctypes.Structure):
     """litho_abbe_options (include/litho_abbe.h): per-call launch-planner options; -1 = not set."""
     _names = ("coarse", "batch", "groups", "xchunk", "tile", "plane_chunk", "w64", "rect", "w64_8192", "xsplit", "xrect",
-              "w64x", "gcombine", "rowpairs", "force_generic", "force_general", "poison")
+              "w64x", "gcombine", "rowpairs", "force_generic", "force_general", "poison", "embed_pn")
     _fields_ = [("size", ctypes.c_int32)] + [(n, ctypes.c_int32) for n in _names]
 
     @classmethod

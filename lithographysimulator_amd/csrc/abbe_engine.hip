@@ -390,7 +390,7 @@ static int env_int(const char* name, int dflt)
 // Tuning / test knobs.  Resolved ONCE per C-ABI call, never per launch: a field of the caller's litho_abbe_options that is
 // >= 0 wins, otherwise the LITHO_ABBE_* environment variable, otherwise the default.
 struct Knobs {
-    int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk, xsplit, rect, xrect, coarse, gcombine, rowpairs, poison;
+    int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk, xsplit, rect, xrect, coarse, gcombine, rowpairs, poison, embed_pn;
     static int pick(const litho_abbe_options* o, size_t off, const char* name, int dflt)
     {
         if (o && off + sizeof(int32_t) <= (size_t)o->size) {
@@ -420,6 +420,7 @@ struct Knobs {
         LITHO_KNOB(gcombine, "LITHO_ABBE_GCOMBINE", 1);
         LITHO_KNOB(rowpairs, "LITHO_ABBE_ROWPAIRS", 0);
         LITHO_KNOB(poison, "LITHO_ABBE_POISON", 0);
+        LITHO_KNOB(embed_pn, "LITHO_ABBE_EMBED_PN", 0);
 #undef LITHO_KNOB
         return k;
     }
@@ -877,6 +878,17 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     S = pl[8];                                               // = S, or the device-side count of the source list
     if (count_out) *count_out = S;
     if (S == 0 || pl[1] < pl[0]) return LITHO_OK;            // no source point / pupil identically zero: nothing to add
+
+    // Embedded call (options.embed_pn = the caller's real grid size, centred in this pn x pn grid with zero margins: how the
+    // host side runs mask sizes that are not N or N/2 on the power-of-two kernels).  The reference rolls the pupil modulo ITS
+    // grid (imageformation.py:63), so the embedding is exact only while no shifted copy of the pupil support leaves the
+    // ORIGINAL grid; otherwise say so before anything is launched and let the caller take the general path at its own size.
+    if (kn.embed_pn > 0) {
+        if (kn.embed_pn >= pn || ((pn - kn.embed_pn) & 1)) return LITHO_E_ARG;
+        const int off = (pn - kn.embed_pn) / 2, last = kn.embed_pn - 1;
+        const bool inside = pl[0] - off + pl[4] >= 0 && pl[1] - off + pl[5] <= last && pl[2] - off + pl[6] >= 0 && pl[3] - off + pl[7] <= last;
+        if (!inside) return LITHO_E_WRAP;
+    }
 
     AbbePlan pp;
     rc = plan_abbe(pp, w, kn, pl, pn, N, planes);

@@ -85,6 +85,62 @@ def _identity(*tensors):
     return tuple(None if t is None else (t.data_ptr(), tuple(t.shape), t._version, str(t.device), t.dtype) for t in tensors)
 
 
+def embeddedSize(pn: int, N: int) -> int:
+    """Grid size the engine runs a pn x pn problem at.  The specialised kernels (and the coarse grid) exist for pn = N and
+    pn = N / 2, N a power of two; any other even size -- a 1000^2 or 3000^2 mask -- would fall to the generic,
+    runtime-predicated kernels (measured 3.4-3.6x slower per source point than the NEXT LARGER power of two).  Such a problem
+    is embedded instead: mask spectrum and pupil centred in a zero-padded N/2 (pn < N/2) or N grid, the same shift list, the
+    centre pn x pn of the accumulated intensity cropped out -- the identical sum, term by term, as long as no shift wraps the
+    pupil around the caller's own grid (the engine checks that on the original size and refuses otherwise)."""
+    if pn == N or 2 * pn == N or (pn & 1):
+        return pn
+    pe = N // 2 if 2 * pn < N else N
+    return pe if pe >= 256 else pn                     # below that the padding costs more than the generic kernels
+
+
+def _plan_workspace(plan, dev, pn, N, pupilF, shifts):
+    """Engine scratch for a call at grid size pn; with a PlanCache, ITS workspace (graphs captured from planned calls hold raw
+    pointers into it) and the identity check of the tensors the plan was made for."""
+    if plan is None:
+        return nat.workspace(dev, pn, N)
+    if (plan.workspace is None or plan.workspace.device != dev or getattr(plan, "_ws_key", None) != (pn, N)):
+        plan.workspace, plan._ws_key = nat.workspace(dev, pn, N), (pn, N)
+    ident = _identity(pupilF) + ((shifts.data_ptr(), shifts._version, str(shifts.device)),)   # not the list's length: a
+    # caller may pass the compacted list at its capacity first (with `count`) and as a [:S] view afterwards
+    if plan.valid and plan.identity is not None and plan.identity != ident:
+        plan.record.valid = 0                          # another pupil / source list, or an in-place write: plan afresh
+    plan.identity = ident
+    return plan.workspace
+
+
+def _embedded_intensity(m, p, sh, count, plan, options, pn, pe, N, out, stacked, planes, dev, pupilF, shifts):
+    """abbeIntensity of a pn x pn problem on the pe x pe grid (embeddedSize): pad, one C call with options.embed_pn = pn,
+    crop.  Returns what abbeIntensity returns, or None when the engine reports LITHO_E_WRAP (nothing accumulated)."""
+    o = (pe - pn) // 2
+    m2 = torch.zeros((pe, pe), dtype=torch.complex64, device=dev)
+    m2[o:o + pn, o:o + pn] = m
+    p2 = torch.zeros((planes, pe, pe), dtype=torch.complex64, device=dev)
+    p2[:, o:o + pn, o:o + pn] = p.view(planes, pn, pn)
+    acc = torch.zeros((planes, pe, pe), dtype=torch.float32, device=dev)
+    ws = _plan_workspace(plan, dev, pe, N, pupilF, shifts)
+    opts = nat.current_options(dict(options or {}, embed_pn=pn))
+    S = ctypes.c_int64(0)
+    with torch.cuda.device(dev):
+        rc = nat.lib().litho_abbe_accumulate_opts(nat.ptr(m2), nat.ptr(p2), planes, nat.ptr(sh),
+                                                  nat.ptr(count) if count is not None else None, sh.shape[0], pe, N,
+                                                  nat.ptr(acc), nat.ptr(ws), ws.numel(), nat.stream_ptr(dev),
+                                                  ctypes.byref(plan.record) if plan is not None else None,
+                                                  ctypes.byref(opts), ctypes.byref(S))
+    if rc == nat.E_WRAP:
+        if plan is not None:
+            plan.record.valid = 0                      # the record was made for the padded grid
+        return None
+    nat.check(rc, "litho_abbe_accumulate_opts")
+    crop = acc[:, o:o + pn, o:o + pn]
+    out += crop if stacked else crop[0]
+    return (out, S.value) if (plan is not None or count is not None) else out
+
+
 def abbeIntensity(maskFT, pupilF, shifts, N, out=None, count=None, plan=None, options=None):
     """The loop of abbeImage (imageformation.py:54-67) for an explicit (dy,dx) list:
     returns / accumulates into the raw fp32 intensity [planes?,pn,pn] BEFORE post-processing.
@@ -93,7 +149,8 @@ def abbeIntensity(maskFT, pupilF, shifts, N, out=None, count=None, plan=None, op
     (sourceShiftsAsync); the call then returns (intensity, S) and the whole image path waits for the
     stream once.  `plan`: optional PlanCache (see there); the call then returns (intensity, S) as well.
     `options`: optional mapping of launch-planner options for THIS call (litho_abbe_options: coarse, batch, groups,
-    xchunk, tile, plane_chunk, ...; see _native.engineOptions), merged over the enclosing engineOptions blocks."""
+    xchunk, tile, plane_chunk, ...; see _native.engineOptions), merged over the enclosing engineOptions blocks.
+    Mask sizes other than N and N / 2 run embedded in the next such grid (embeddedSize)."""
     pn = _square(maskFT, "maskFT")
     if pupilF.dim() not in (2, 3) or tuple(pupilF.shape[-2:]) != (pn, pn) or (pupilF.dim() == 3 and pupilF.shape[0] < 1):
         # e.g. a default Pupil() (pixelNumber 64) with a 256^2 mask: the reference fails at pf * maskFFFT
@@ -116,23 +173,16 @@ def abbeIntensity(maskFT, pupilF, shifts, N, out=None, count=None, plan=None, op
                          f"{out.dtype} {tuple(out.shape)} on {out.device}, contiguous={out.is_contiguous()}")
     rc = nat.lib().litho_abbe_workspace_bytes(pn, int(N), ctypes.byref(ctypes.c_size_t(0)))
     nat.check(rc, "abbeImage")
-    if plan is not None:
-        # the planned call's scratch belongs to the PlanCache (graphs captured from it hold raw pointers into it)
-        if (plan.workspace is None or plan.workspace.device != m.device
-                or getattr(plan, "_ws_key", None) != (pn, int(N))):
-            plan.workspace, plan._ws_key = nat.workspace(dev, pn, int(N)), (pn, int(N))
-        ws = plan.workspace
-        ident = _identity(pupilF) + ((shifts.data_ptr(), shifts._version, str(shifts.device)),)   # not the list's length: a
-        # caller may pass the compacted list at its capacity first (with `count`) and as a [:S] view afterwards
-        if plan.valid and plan.identity is not None and plan.identity != ident:
-            plan.record.valid = 0                      # another pupil / source list, or an in-place write: plan afresh
-        plan.identity = ident
-    else:
-        ws = nat.workspace(dev, pn, int(N))
+    if count is not None and (count.dtype != torch.int32 or count.numel() != 1 or count.device != m.device):
+        raise ShapeError("count must be a 1-element int32 tensor on the mask's device")
+    pe = embeddedSize(pn, int(N))
+    if pe != pn and nat.EMBED_ODD_SIZES:
+        done = _embedded_intensity(m, p, sh, count, plan, options, pn, pe, int(N), out, stacked, planes, dev, pupilF, shifts)
+        if done is not None:
+            return done                                # (None: a shift wraps the pupil around the caller's grid -- general path below)
+    ws = _plan_workspace(plan, dev, pn, int(N), pupilF, shifts)
     opts = nat.current_options(options)
     with torch.cuda.device(dev):
-        if count is not None and (count.dtype != torch.int32 or count.numel() != 1 or count.device != m.device):
-            raise ShapeError("count must be a 1-element int32 tensor on the mask's device")
         if opts is not None:
             S = ctypes.c_int64(0)
             nat.check(nat.lib().litho_abbe_accumulate_opts(nat.ptr(m), nat.ptr(p), planes, nat.ptr(sh),

@@ -242,6 +242,82 @@ def test_shift_one_sample_short_of_wrapping_and_one_past(L, dev, pn, axis, sign)
             _check(got, ref, f"{pn}^2 shift {big} on axis {axis} (wraps: {past}), coarse={coarse}")
 
 
+# ------------------------------------------------------------------ mask sizes that are neither N nor N / 2: embedded evaluation
+@pytest.mark.parametrize("pn,ps,pe", [(200, 25, 256), (1000, 25, 1024), (1500, 25, 2048), (768, 25, 1024), (300, 10, 512)])
+def test_odd_mask_sizes_run_embedded_and_match_the_oracle(L, dev, monkeypatch, pn, ps, pe):
+    """A 1000^2 (1500^2, 768^2 ...) mask is neither N nor N / 2: instead of the generic kernels the host side pads mask
+    spectrum and pupil into the next such grid, runs the power-of-two kernels (coarse grid included) with the ORIGINAL size
+    as options.embed_pn, and crops.  Same sum term by term: single plane, a stack, a pre-filled `out`, through abbeImage, with
+    a PlanCache -- against the oracle and against the un-embedded generic evaluation."""
+    o = O()
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    gen = torch.Generator().manual_seed(pn)
+    geo = (torch.rand(pn, pn, generator=gen) < 0.5).to(torch.int16)
+    mask = L.Mask(geo, ps, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, ps, WL)
+    assert L.embeddedSize(pn, N) == pe
+    pupil = L.Pupil(pn, WL, NA, f16([0, 0, 0.01, 0, 80, 0.01]), dev).generatePupilFunction()
+    bitmap = L.LightSource(0.4, 0.8, pn, NA, device=dev).generateAnnular()
+    sh = L.sourceShifts(bitmap, pn)
+    K = 12 if pn <= 1000 else 5
+    sel = sh[(torch.arange(K, device=dev) * sh.shape[0]) // K].contiguous()
+    ref = o.abbe_raw(mft.cpu(), pupil.cpu(), sel.cpu(), N)
+    for coarse in (1, 2, 0):
+        got = L.abbeIntensity(mft, pupil, sel, N, options={"coarse": coarse}).cpu()
+        plan = nat().last_plan()
+        assert plan["general"] == 0 and plan["variant"] >= 0, plan               # a specialised kernel family, at the padded size
+        assert plan["coarse_grid"] == (1 if coarse == 2 and 2 * pe == N else 0), (coarse, plan)
+        _check(got, ref, f"{pn}^2 (N {N}) embedded in {pe}^2, coarse={coarse}, kernels {nat().last_kernels()}")
+    monkeypatch.setattr(nat(), "EMBED_ODD_SIZES", False)
+    plain = L.abbeIntensity(mft, pupil, sel, N).cpu()
+    assert nat().last_plan()["variant"] == (-1 if pn & (pn - 1) else nat().last_plan()["variant"])
+    monkeypatch.setattr(nat(), "EMBED_ODD_SIZES", True)
+    _check(plain, ref, f"{pn}^2 un-embedded")
+    # a stack, accumulated into a pre-filled buffer
+    stack = L.throughFocusPupils(pn, WL, NA, f16([0, 0, 0.01, 0, 80, 0.01]), [-60.0, 40.0], dev)
+    pre = torch.rand(2, pn, pn, generator=gen).to(dev) * float(ref.max()) * 0.2
+    both = L.abbeIntensity(mft, stack, sel, N, out=pre.clone()).cpu()
+    for k in range(2):
+        want = pre[k].cpu().double() + o.abbe_raw(mft.cpu(), stack[k].cpu(), sel.cpu(), N).double()
+        _check(both[k], want, f"{pn}^2 stack plane {k}, pre-filled out")
+    # end to end, with a PlanCache (second call plans from the record, on the padded grid)
+    few = torch.zeros_like(bitmap)
+    pts = torch.argwhere(bitmap)[(torch.arange(K, device=dev) * sh.shape[0]) // K]
+    few[pts[:, 0], pts[:, 1]] = 1
+    cache = L.PlanCache()
+    img1 = L.abbeImage(mask, mft, pupil, few, ps, mask.deltaK, WL, True, dev, plan_cache=cache)
+    img2 = L.abbeImage(mask, mft, pupil, few, ps, mask.deltaK, WL, True, dev, plan_cache=cache)
+    assert nat().last_plan()["planned_from_record"] == 1 and cache.record.pn == pe and torch.equal(img1, img2)
+    want = o.post_process(o.abbe_raw(mft.cpu(), pupil.cpu(), o.source_shifts(few.cpu(), pn), N), eps)
+    assert img1.shape == want.shape
+    _check(img1.cpu(), want, f"{pn}^2 abbeImage end to end")
+
+
+@pytest.mark.parametrize("pn", [200, 1000])
+def test_embedded_evaluation_refuses_shifts_that_wrap_the_original_grid(L, dev, pn):
+    """The reference rolls the pupil modulo ITS grid (imageformation.py:63).  In the padded grid a large shift has room
+    that the original grid does not: the engine tests the wrap on the ORIGINAL size (LITHO_E_WRAP, nothing accumulated) and
+    the host side falls back to the general path at the caller's size -- one sample short of wrapping runs embedded."""
+    o = O()
+    gen = torch.Generator().manual_seed(3 * pn)
+    mask = L.Mask((torch.rand(pn, pn, generator=gen) < 0.5).to(torch.int16), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    pupil = L.Pupil(pn, WL, NA, f16([0, 0, 0, 0, 50]), dev).generatePupilFunction()
+    c, h = pn // 2, pn // 4
+    edge = -(c - h)                                                     # the pupil's first row lands on row 0
+    for past, expect_general in ((0, 0), (1, 1)):
+        sel = torch.tensor([[3, -5], [edge - past, 7], [-11, 17]], dtype=torch.int32, device=dev)
+        pre = torch.full((pn, pn), 2.5, device=dev)
+        got = L.abbeIntensity(mft, pupil, sel, N, out=pre.clone(), options={"coarse": 2}).cpu()
+        plan = nat().last_plan()
+        assert plan["general"] == expect_general, (past, plan)
+        assert plan["box_rows"] == (pn if past else 2 * h + 1), plan          # general mode runs at the caller's size
+        want = 2.5 + o.abbe_raw(mft.cpu(), pupil.cpu(), sel.cpu(), N).double()
+        _check(got, want, f"{pn}^2 shift {edge - past} (wraps the original grid: {past})")
+
+
 def test_environment_variables_remain_a_fallback_and_options_win(L, dev, monkeypatch):
     """Options passed per call beat the LITHO_ABBE_* variables; a field the caller leaves unset falls back to the variable,
     then to the default."""

@@ -335,7 +335,9 @@ def abbeImage(mask, maskFT: torch.Tensor, pupilF: torch.Tensor, lightsource: tor
         planes = pupilF.shape[0] if pupilF.dim() == 3 else 1
         r = plan_cache.record
         ident = _identity(pupilF, lightsource)
-        if (plan_cache.shifts is None or not plan_cache.valid or (r.pn, r.N, r.planes) != (pixelNumber, int(N), planes)
+        # (the record is made at the size the engine ran at: the caller's, or the padded grid of an embedded evaluation)
+        if (plan_cache.shifts is None or not plan_cache.valid or r.pn not in (pixelNumber, embeddedSize(pixelNumber, int(N)))
+                or (r.N, r.planes) != (int(N), planes)
                 or plan_cache.image_identity != ident):
             plan_cache.invalidate()
             plan_cache.image_identity = ident

@@ -94,8 +94,12 @@ def embeddedSize(pn: int, N: int) -> int:
     pupil around the caller's own grid (the engine checks that on the original size and refuses otherwise)."""
     if pn == N or 2 * pn == N or (pn & 1):
         return pn
-    pe = N // 2 if 2 * pn < N else N
-    return pe if pe >= 256 else pn                     # below that the padding costs more than the generic kernels
+    # Measured (scripts/embed_ab.py, us per source point, embedded / plain): 1000^2 at N 2048 2.48 / 8.38, 2000^2 at N 4096
+    # 9.2 / 33.6, 1500^2 at N 2048 7.4 / 16.2, 3000^2 at N 4096 35.2 / 58.8, 2000^2 at N 2048 8.6 / 29.1; N = 4 pn (10 nm
+    # pixels): 256^2 0.63 / 0.94, 1024^2 5.9 / 6.2, 2048^2 28.4 / 37.7; but 300^2 in a 512 grid 0.52 / 0.50.
+    if 2 * pn < N:
+        return N // 2 if N // 2 >= 256 else pn         # N / 2: the coarse grid applies
+    return N if N >= 1024 else pn                      # N: the full-output kernels; below 1024 the padding does not pay
 
 
 def _plan_workspace(plan, dev, pn, N, pupilF, shifts):

@@ -151,11 +151,14 @@ def test_other_fft_ratios_vs_golden(golden, L, dev, ps):
     assert rel_max(img, ref) < TOL_IMAGE_MAX
 
 
-@pytest.mark.parametrize("pn,ps", [(512, 48), (512, 10), (1024, 48), (256, 10), (256, 48), (2048, 48)])
-def test_other_fft_ratios_mid_size_vs_oracle(L, dev, pn, ps):
+@pytest.mark.parametrize("pn,ps,embed", [(512, 48, True), (512, 10, False), (512, 10, True), (1024, 48, True), (256, 10, False), (256, 10, True),
+                                         (256, 48, True), (2048, 48, True)])
+def test_other_fft_ratios_mid_size_vs_oracle(L, dev, monkeypatch, pn, ps, embed):
     """N = pn (pixelSize 48: the RL = 0 pruned kernels, 9 live input slots) and N = 4 pn (pixelSize 10: RL = 2) at
-    sizes where a line spans whole workgroups, against the CPU oracle's op chain and its post-process."""
+    sizes where a line spans whole workgroups, against the CPU oracle's op chain and its post-process.  N = 4 pn twice: on
+    the RL = 2 kernels (host-side embedding off) and as a caller gets it since round 4 (embedded in the N / 2 grid: RL = 1)."""
     from lithographysimulator_amd import _native as nat
+    monkeypatch.setattr(nat, "EMBED_ODD_SIZES", embed)
     from lithographysimulator_amd.synthetic import bernoulli_mask
     o = O()
     mask = L.Mask(bernoulli_mask(pn), ps, dev)
@@ -166,7 +169,7 @@ def test_other_fft_ratios_mid_size_vs_oracle(L, dev, pn, ps):
     sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateQuasar(4, -math.pi / 8), pn)
     sel = sh[(torch.arange(12 if pn < 2048 else 4, device=dev) * sh.shape[0]) // (12 if pn < 2048 else 4)]
     raw = L.abbeIntensity(mft, pf, sel, N).cpu()
-    assert nat.last_plan()["variant"] == (0 if ps == 48 else 2) and nat.last_plan()["general"] == 0
+    assert nat.last_plan()["variant"] == (0 if ps == 48 else 1 if embed else 2) and nat.last_plan()["general"] == 0
     ref = o.abbe_raw(mft.cpu(), pf.cpu(), sel.cpu(), N)
     assert rel_max(raw, ref) < TOL_IMAGE_MAX and rel_l2(raw, ref) < TOL_IMAGE_L2
     img = L.postProcess(raw.to(dev), eps).cpu()

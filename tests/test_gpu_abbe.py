@@ -811,6 +811,51 @@ def test_config2_full_source_vs_reference_golden(golden, L, dev, monkeypatch, pa
         assert e_n < 1e-4
 
 
+@pytest.mark.parametrize("path", ["coarse", "direct"])
+def test_config3_rank_shard_vs_reference_golden(golden, L, dev, monkeypatch, path):
+    """ONE RANK'S SHARD of BASELINE config 3 at 8 GPUs against the reference ITSELF (golden g14: source points [0, 24764)
+    of the 2048^2 quasar list = distributed.shard_bounds(198108, 0, 8) through the reference's own abbeImage, its sequential
+    fp32 sum of 24,764 images): the per-rank work of the 8-GPU run on dense reference-made data -- 2,064 default batches and
+    32 slab folds on the coarse grid, the same on the direct path.  Tolerance as for config 2 in full (the reference's own
+    sequential fp32 sum is that far from exact); the observed figures are printed."""
+    import os
+    from lithographysimulator_amd import _native as nat
+    from lithographysimulator_amd.distributed import shard_bounds
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    from conftest import GOLDEN
+    if not os.path.exists(os.path.join(GOLDEN, "g14_config3_rank_shard.npz")):
+        pytest.skip("golden g14 not generated (tests/golden/make_golden.py g14: 1.5 h of CPU)")
+    g = golden("g14_config3_rank_shard.npz")
+    pn = 2048
+    if path == "direct":
+        _opt(monkeypatch, coarse="0")
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateQuasar(4, -math.pi / 8), pn)
+    lo, hi, S = (int(v) for v in g["cfg3shard_range"])
+    assert sh.shape[0] == S == 198108 and (lo, hi) == shard_bounds(S, 0, 8)
+    sel = sh[lo:hi]
+    assert np.array_equal(sel[[0, -1]].cpu().numpy(), g["cfg3shard_first_last_shift"])
+    pf = L.Pupil(pn, WL, NA, f16(DEMO_AB), dev).generatePupilFunction()
+    raw = L.abbeIntensity(mft, pf, sel, N)
+    plan = nat.last_plan()
+    assert plan["coarse_grid"] == (1 if path == "coarse" else 0) and plan["batch"] == 12 and plan["launches"] == 2064, plan
+    final = L.postProcess(raw, eps).cpu()
+    raw = raw.cpu()
+    for tag, img in (("raw", raw), ("final", final)):
+        mx = float(g[f"cfg3shard_{tag}_max"])
+        e_crop = float((crop_center(img).double() - torch.from_numpy(g[f"cfg3shard_{tag}_crop"]).double()).abs().max() / mx)
+        e_grid = float(np.abs(img[::16, ::16].numpy().astype(np.float64) - g[f"cfg3shard_{tag}_stride16"]).max() / mx)
+        e_rows = float(np.abs(img.double().sum(1).numpy() - g[f"cfg3shard_{tag}_rowsum"]).max() / g[f"cfg3shard_{tag}_rowsum"].max())
+        e_cols = float(np.abs(img.double().sum(0).numpy() - g[f"cfg3shard_{tag}_colsum"]).max() / g[f"cfg3shard_{tag}_colsum"].max())
+        e_sum = abs(float(img.double().sum()) / float(g[f"cfg3shard_{tag}_sum"]) - 1)
+        e_max = abs(float(img.max()) / mx - 1)
+        print(f"config 3, rank 0 of 8 ({hi - lo} points) vs the reference, {path} path, {tag}: crop {e_crop:.2e}, stride-16 grid "
+              f"{e_grid:.2e}, row sums {e_rows:.2e}, column sums {e_cols:.2e}, total {e_sum:.2e}, max {e_max:.2e}")
+        assert max(e_crop, e_grid, e_max) < 1e-4 and max(e_rows, e_cols, e_sum) < 2e-5
+
+
 def few_beam_closed_form(P, shifts, orders, amps, pn, N):
     P = P.cpu().to(torch.complex128).numpy()
     sh = shifts.cpu().numpy().astype(np.int64)

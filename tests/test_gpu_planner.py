@@ -292,6 +292,10 @@ def test_odd_mask_sizes_run_embedded_and_match_the_oracle(L, dev, monkeypatch, p
     want = o.post_process(o.abbe_raw(mft.cpu(), pupil.cpu(), o.source_shifts(few.cpu(), pn), N), eps)
     assert img1.shape == want.shape
     _check(img1.cpu(), want, f"{pn}^2 abbeImage end to end")
+    img3 = L.abbeImage(mask, mft, pupil, few, ps, mask.deltaK, WL, True, dev)            # the default call: device-side source count
+    assert nat().last_plan()["planned_from_record"] == 0 and torch.equal(img3, img1)
+    norm = L.abbeImage(mask, mft, pupil, few, ps, mask.deltaK, WL, True, dev, normalize=True)
+    assert rel_max((norm * K).cpu(), img1.cpu()) < 1e-6
 
 
 @pytest.mark.parametrize("pn", [200, 1000])

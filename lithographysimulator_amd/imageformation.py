@@ -70,10 +70,11 @@ class PlanCache:
         self.workspace = None       # engine scratch of the planned calls (kept alive for captured graphs)
         self.identity = None        # what the record was made for (see _identity): abbeIntensity's pupil + shift list
         self.image_identity = None  # ... and abbeImage's pupil + source bitmap
+        self.padded_pupil = None    # embedded evaluation (mask sizes other than N, N / 2): the zero-padded pupil (stack)
 
     def invalidate(self):
         self.record.valid = 0
-        self.shifts = self.count = self.S = self.identity = self.image_identity = None
+        self.shifts = self.count = self.S = self.identity = self.image_identity = self.padded_pupil = None
 
     @property
     def valid(self):
@@ -123,10 +124,16 @@ def _embedded_intensity(m, p, sh, count, plan, options, pn, pe, N, out, stacked,
     o = (pe - pn) // 2
     m2 = torch.zeros((pe, pe), dtype=torch.complex64, device=dev)
     m2[o:o + pn, o:o + pn] = m
-    p2 = torch.zeros((planes, pe, pe), dtype=torch.complex64, device=dev)
-    p2[:, o:o + pn, o:o + pn] = p.view(planes, pn, pn)
     acc = torch.zeros((planes, pe, pe), dtype=torch.float32, device=dev)
     ws = _plan_workspace(plan, dev, pe, N, pupilF, shifts)
+    # the padded pupil (stack) of a planned sequence is made once: same pupil tensor (identity checked above), same padding
+    p2 = plan.padded_pupil if (plan is not None and plan.valid and plan.padded_pupil is not None
+                               and tuple(plan.padded_pupil.shape) == (planes, pe, pe)) else None
+    if p2 is None:
+        p2 = torch.zeros((planes, pe, pe), dtype=torch.complex64, device=dev)
+        p2[:, o:o + pn, o:o + pn] = p.view(planes, pn, pn)
+        if plan is not None:
+            plan.padded_pupil = p2
     opts = nat.current_options(dict(options or {}, embed_pn=pn))
     S = ctypes.c_int64(0)
     with torch.cuda.device(dev):

@@ -152,6 +152,12 @@ int litho_abbe_accumulate_opts(const void *maskFT, const void *pupil, int planes
                                void *workspace, size_t workspace_bytes, void *stream, litho_abbe_plan *plan,
                                const litho_abbe_options *options, int64_t *count_host);
 
+/* ---- The two data movements of an embedded evaluation (options.embed_pn above; no reference counterpart -- the reference
+ * runs any size through torch.fft, imageformation.py:32-45): centre complex64 [planes,pn,pn] in a zero-filled
+ * [planes,pe,pe] (pe - pn even), and dst[planes,pn,pn] += the centre pn x pn of src fp32 [planes,pe,pe]. */
+int litho_embed_c64(const void *src, int planes, int pn, void *dst, int pe, void *stream);
+int litho_crop_add_f32(const float *src, int planes, int pe, float *dst, int pn, void *stream);
+
 /* ---- Single-point field: calculateFFTAerial(pf, maskFFFT, pixelNumber, N)
  * (imageformation.py:32-45).  field = complex64 [pn,pn].  Reads back 16 bytes. */
 int litho_abbe_field(const void *pf, const void *maskFT, int pn, int N, void *field,

@@ -35,6 +35,8 @@ _SIGNATURES = {
                                               c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, POINTER(c_int64)]),
     "litho_abbe_accumulate_opts": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int,
                                            c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, POINTER(c_int64)]),
+    "litho_embed_c64": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "litho_crop_add_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "litho_abbe_field": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "litho_postprocess_size": (c_int, [c_int, c_double, POINTER(c_int)]),
     "litho_postprocess": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p]),

@@ -282,6 +282,26 @@ static int osa_n(int j) { return (int)std::ceil(0.5 * (-3.0 + std::sqrt(9.0 + 8.
 
 static double factorial(int v) { double f = 1.0; for (int i = 2; i <= v; ++i) f *= i; return f; }
 
+// ----------------------------------------------------------------------------------
+// Embedded evaluation: centre a pn x pn complex array in a zero-padded pe x pe one, and add the
+// centre pn x pn of a pe x pe real image to a pn x pn one.  One thread per destination element; blockIdx.z = plane.
+// ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_embed_c64(const float2* __restrict__ src, int pn, float2* __restrict__ dst, int pe)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= pe) return;
+    const int o = (pe - pn) / 2, sx = x - o, sy = y - o;
+    const bool in = sx >= 0 && sx < pn && sy >= 0 && sy < pn;
+    dst[((size_t)blockIdx.z * pe + y) * pe + x] = in ? src[((size_t)blockIdx.z * pn + sy) * pn + sx] : make_float2(0.f, 0.f);
+}
+__global__ __launch_bounds__(256) void k_crop_add_f32(const float* __restrict__ src, int pe, float* __restrict__ dst, int pn)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= pn) return;
+    const int o = (pe - pn) / 2;
+    dst[((size_t)blockIdx.z * pn + y) * pn + x] += src[((size_t)blockIdx.z * pe + y + o) * pe + x + o];
+}
+
 }  // namespace litho
 
 extern "C" {
@@ -433,6 +453,25 @@ int litho_postprocess(const float* raw, int planes, int pn, double epsilon, floa
     const float rs = (float)(1.0 / scale);
     hipLaunchKernelGGL(k_postprocess<false>, dim3((n_out + 255) / 256, n_out, planes), dim3(256), 0, (hipStream_t)stream,
                        raw, pn, ns, pW, n_out, rs, out, 1.0f, 0.0f, (unsigned char*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return LITHO_OK;
+}
+
+int litho_embed_c64(const void* src, int planes, int pn, void* dst, int pe, void* stream)
+{
+    using namespace litho;
+    if (!src || !dst || planes < 1 || pn < 1 || pe < pn || ((pe - pn) & 1)) return LITHO_E_ARG;
+    hipLaunchKernelGGL(k_embed_c64, dim3((pe + 255) / 256, pe, planes), dim3(256), 0, (hipStream_t)stream, (const float2*)src, pn,
+                       (float2*)dst, pe);
+    HIP_TRY(hipGetLastError());
+    return LITHO_OK;
+}
+
+int litho_crop_add_f32(const float* src, int planes, int pe, float* dst, int pn, void* stream)
+{
+    using namespace litho;
+    if (!src || !dst || planes < 1 || pn < 1 || pe < pn || ((pe - pn) & 1)) return LITHO_E_ARG;
+    hipLaunchKernelGGL(k_crop_add_f32, dim3((pn + 255) / 256, pn, planes), dim3(256), 0, (hipStream_t)stream, src, pe, dst, pn);
     HIP_TRY(hipGetLastError());
     return LITHO_OK;
 }

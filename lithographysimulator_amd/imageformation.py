@@ -121,19 +121,20 @@ def _plan_workspace(plan, dev, pn, N, pupilF, shifts):
 def _embedded_intensity(m, p, sh, count, plan, options, pn, pe, N, out, stacked, planes, dev, pupilF, shifts):
     """abbeIntensity of a pn x pn problem on the pe x pe grid (embeddedSize): pad, one C call with options.embed_pn = pn,
     crop.  Returns what abbeIntensity returns, or None when the engine reports LITHO_E_WRAP (nothing accumulated)."""
-    o = (pe - pn) // 2
-    m2 = torch.zeros((pe, pe), dtype=torch.complex64, device=dev)
-    m2[o:o + pn, o:o + pn] = m
+    lib, st = nat.lib(), nat.stream_ptr(dev)
+    m2 = torch.empty((pe, pe), dtype=torch.complex64, device=dev)
     acc = torch.zeros((planes, pe, pe), dtype=torch.float32, device=dev)
     ws = _plan_workspace(plan, dev, pe, N, pupilF, shifts)
     # the padded pupil (stack) of a planned sequence is made once: same pupil tensor (identity checked above), same padding
     p2 = plan.padded_pupil if (plan is not None and plan.valid and plan.padded_pupil is not None
                                and tuple(plan.padded_pupil.shape) == (planes, pe, pe)) else None
-    if p2 is None:
-        p2 = torch.zeros((planes, pe, pe), dtype=torch.complex64, device=dev)
-        p2[:, o:o + pn, o:o + pn] = p.view(planes, pn, pn)
-        if plan is not None:
-            plan.padded_pupil = p2
+    with torch.cuda.device(dev):
+        nat.check(lib.litho_embed_c64(nat.ptr(m), 1, pn, nat.ptr(m2), pe, st), "litho_embed_c64")
+        if p2 is None:
+            p2 = torch.empty((planes, pe, pe), dtype=torch.complex64, device=dev)
+            nat.check(lib.litho_embed_c64(nat.ptr(p), planes, pn, nat.ptr(p2), pe, st), "litho_embed_c64")
+            if plan is not None:
+                plan.padded_pupil = p2
     opts = nat.current_options(dict(options or {}, embed_pn=pn))
     S = ctypes.c_int64(0)
     with torch.cuda.device(dev):
@@ -147,8 +148,8 @@ def _embedded_intensity(m, p, sh, count, plan, options, pn, pe, N, out, stacked,
             plan.record.valid = 0                      # the record was made for the padded grid
         return None
     nat.check(rc, "litho_abbe_accumulate_opts")
-    crop = acc[:, o:o + pn, o:o + pn]
-    out += crop if stacked else crop[0]
+    with torch.cuda.device(dev):
+        nat.check(lib.litho_crop_add_f32(nat.ptr(acc), planes, pe, nat.ptr(out), pn, st), "litho_crop_add_f32")
     return (out, S.value) if (plan is not None or count is not None) else out
 
 

@@ -54,6 +54,9 @@ WORKLOADS = {
     "cfg3": (2048, "quasar", DEMO_AB, 1, "2048x2048 bernoulli mask, quasar(4,-pi/8) 0.4-0.8, 10-term Zernike pupil"),
     "cfg4": (4096, "annular", [0, 0, 0, 0, 100], 1, "4096x4096 bernoulli mask, annular 0.4-0.8, defocus-only pupil"),
     "cfg5": (2048, "quasar", DEMO_AB, 32, "2048x2048 bernoulli mask x 32-plane through-focus stack (defocus -310..310 nm), quasar(4,-pi/8) 0.4-0.8"),
+    # NOT a BASELINE configuration: config 3's optics on a mask whose size is not a power of two -- evaluated embedded in the
+    # 2048^2 grid; rides in extra_workloads so that the path has a driver-observed number
+    "odd2000": (2000, "quasar", DEMO_AB, 1, "NOT A BASELINE CONFIG: 2000x2000 bernoulli mask (not a power of two: embedded evaluation), quasar(4,-pi/8) 0.4-0.8, 10-term Zernike pupil"),
 }
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_TFLOPS = 157.3              # MI355X_MICROARCH.md: peak fp32 vector
@@ -153,10 +156,12 @@ class Workload:
         return L.postProcess(L.abbeIntensity(self.maskFT, self.pupil, sh, self.N), self.epsilon)
 
 
-def kernel_profile(nat, prof, plan, pn, N):
-    """Per-kernel-class figures of one profiled call (HIP events recorded by the library on the launch stream)."""
-    lines = {"xpass": plan["box_rows"], "ypass": pn}            # lines transformed per T item
-    n_exec = pn if plan.get("coarse_grid") else N                # coarse-grid path: pn-point transforms on the grid q = 2 v
+def kernel_profile(nat, prof, plan, pn, N, pe=None):
+    """Per-kernel-class figures of one profiled call (HIP events recorded by the library on the launch stream).
+    pe: the grid the engine ran at when the problem was evaluated embedded (a mask size other than N and N / 2)."""
+    pe = pe or pn
+    lines = {"xpass": plan["box_rows"], "ypass": pe}            # lines transformed per T item
+    n_exec = pe if plan.get("coarse_grid") else N                # coarse-grid path: pe-point transforms on the grid q = 2 v
     line_flops = 5.0 * n_exec * math.log2(n_exec)                # nominal FFT flops of one transformed line
     kern = {}
     for k in ("xpass", "ypass"):
@@ -270,14 +275,15 @@ def extra_workload(torch, nat, dev, name, shard=None, steps=1, warm_points=0, pr
     L.abbeIntensity(w.maskFT, w.pupil if w.planes == 1 else w.pupil[:2], sh, w.N)
     torch.cuda.synchronize()
     prof = nat.last_profile()
-    kern, n_exec = kernel_profile(nat, prof, nat.last_plan(), w.pn, w.N)
+    kern, n_exec = kernel_profile(nat, prof, nat.last_plan(), w.pn, w.N, L.embeddedSize(w.pn, w.N))
     nat.set_profiling(False)
     both = kern["xpass"]["total_ms"] + kern["ypass"]["total_ms"]
     dom = "ypass" if kern["ypass"]["total_ms"] >= 0.95 * kern["xpass"]["total_ms"] else "xpass"   # as in the headline
-    out = {"workload": f"BASELINE {name}: {w.desc}" + (f" [{note}]" if note else ""), "steps": steps,
+    out = {"workload": (f"BASELINE {name}: " if name.startswith("cfg") else f"{name}: ") + w.desc + (f" [{note}]" if note else ""), "steps": steps,
            "ms_per_step": elapsed / steps * 1e3, "value": units * steps / elapsed, "unit": "source-pt*px/s",
            "source_points": S, "source_points_full": w.S_full, "planes": w.planes, "pn": w.pn, "fft_n": w.N,
            "executed_fft_n": n_exec, "image_shape": list(image.shape), "plan": plan,
+           "embedded_in": L.embeddedSize(w.pn, w.N) if L.embeddedSize(w.pn, w.N) != w.pn else None,
            "dominant_kernel": kern[dom]["kernel"], "dominant_kernel_time_frac": kern[dom]["total_ms"] / both if both else None,
            "dominant_kernel_valu_frac": kern[dom]["achieved_TFLOPs"] / VALU_PEAK_TFLOPS,
            "kernels": {k: {"kernel": v["kernel"], "avg_launch_ms": v["avg_launch_ms"], "items_per_launch": v["items_per_launch"]}
@@ -418,7 +424,7 @@ def main():
     plan = nat.last_plan()
     nat.set_profiling(False)
     copy_gbs, fill_gbs = measured_ceilings(torch, dev)
-    kern, n_exec = kernel_profile(nat, prof, plan, pn, N)
+    kern, n_exec = kernel_profile(nat, prof, plan, pn, N, L.embeddedSize(pn, N))
     # The two pass kernels share the time almost evenly (50.3 % / 49.1 % under rocprofv3) and trade places from run to
     # run; `roofline` describes the y-pass -- the VALU-bound one, for which a flop fraction means something -- unless the
     # x-pass leads by more than 5 %.  Both kernels carry their own figures (and their measured bound) under `kernels`.
@@ -492,7 +498,8 @@ def main():
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic",
-           "config": {"workload": f"BASELINE {args.workload}: {w.desc}" + (f" [{shard_note}]" if shard_note else ""),
+           "config": {"workload": (f"BASELINE {args.workload}: " if args.workload.startswith("cfg") else f"{args.workload}: ") + w.desc
+                                  + (f" [{shard_note}]" if shard_note else ""),
                       "pn": pn, "fft_n": N, "executed_fft_n": n_exec, "source_points": S, "source_points_full": S_full, "planes": planes,
                       "points_per_rank": math.ceil(S / world), "pixel_size": PS, "wavelength": WL, "NA": NA,
                       "parallelism": f"source-point shards x{world}, one all-reduce" if world > 1 else "single GPU",
@@ -512,7 +519,8 @@ def main():
         extras = []
         for name, kw in (("cfg1", dict(steps=5, profile_points=1 << 30)), ("cfg2", dict(steps=2, profile_points=4800)),
                          ("cfg4", dict(shard=(0, 8), steps=1, warm_points=600, profile_points=600)),
-                         ("cfg5", dict(steps=1, warm_points=240, profile_points=240))):
+                         ("cfg5", dict(steps=1, warm_points=240, profile_points=240)),
+                         ("odd2000", dict(steps=1, warm_points=480, profile_points=480))):
             try:
                 extras.append(extra_workload(torch, nat, dev, name, cpu=not args.no_cpu_baseline, **kw))
             except Exception as exc:                              # an extra must never cost the headline line

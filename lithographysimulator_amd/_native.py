@@ -89,6 +89,9 @@ def check(rc, what):
         raise RuntimeError(f"{what}: HIP error: {lib().litho_last_error().decode()}")
     if rc == E_WORKSPACE:
         raise RuntimeError(f"{what}: workspace too small")
+    if rc == E_WRAP:
+        raise RuntimeError(f"{what}: embedded evaluation refused -- a shift wraps the pupil around the original grid "
+                           "(call with the original size; abbeIntensity does that by itself)")
     raise ValueError(f"{what}: unsupported or invalid argument (pn must be even, 2..16384; N a power of two, "
                      "16..16384)")
 

@@ -521,6 +521,46 @@ def g14_config3_rank_shard():
     save("g14_config3_rank_shard.npz", **out)
 
 
+def g15_config5_stack_run():
+    """BASELINE config 5's stack on DENSE data through several launch batches per plane: 8 of its 32 planes (defocus -310 + 80 j
+    nm, j = 0..7) x 240 CONSECUTIVE source points [90000, 90240) of the 2048^2 quasar list, by the reference's Python loop over
+    Pupil(...) + abbeImage(...) (there is no stack API in the reference; imageformation.py:47-77, pupil.py:91-92): 20 of the
+    engine's default 12-point batches per plane.  Per plane: centre crop, stride-32 grid, fp64 row / column sums, max and sum
+    of the raw intensity and of the final image.  About ten minutes of this container's CPUs."""
+    print("G15 config-5 stack, 8 planes x 240 consecutive points at 2048^2")
+    pn, lo, n = 2048, 90000, 240
+    out = {}
+    defocus = [-310 + 80 * j for j in range(8)]
+    out["defocus_nm"] = np.array(defocus, dtype=np.float64)
+    mk = quiet(ref_mask.Mask, bernoulli_mask(pn), PS, CPU)
+    mft = mk.fraunhofer(WL, True)
+    full = source("quasar", pn, 0.4, 0.8)
+    pts = torch.argwhere(full)
+    bm = torch.zeros_like(full)
+    sel = pts[lo:lo + n]
+    bm[sel[:, 0], sel[:, 1]] = 1
+    out["range"] = np.array([lo, lo + n, pts.shape[0]], dtype=np.int64)
+    out["first_last_shift"] = shifts_of(bm, pn)[[0, -1]]
+    keys = ("crop", "rowsum", "colsum", "max", "sum", "stride32")
+    acc = {f"{kind}_{k}": [] for kind in ("raw", "final") for k in keys}
+    for i, d in enumerate(defocus):
+        ab = list(DEMO_AB); ab[4] = d
+        pf = pupil_fn(pn, ab)
+        final, raw = full_image_with_raw(mk, mft, pf, bm)
+        tmp = {}
+        for kind, img in (("raw", raw), ("final", final)):
+            crop_stats(kind, img, tmp, crop=64)
+            tmp[f"{kind}_stride32"] = img[::32, ::32].contiguous()
+            for k in keys:
+                v = tmp[f"{kind}_{k}"]
+                acc[f"{kind}_{k}"].append(v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+        print(f"   plane {i} d={d:5d} nm  raw sum {float(tmp['raw_sum']):.6e}", flush=True)
+    for k, v in acc.items():
+        out[k] = np.stack(v)
+    out["final_shape"] = tmp["final_shape"]
+    save("g15_config5_stack_run.npz", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     if os.environ.get("LITHO_GOLDEN_THREADS"):
@@ -529,4 +569,4 @@ if __name__ == "__main__":
     for g in which:
         {"g1": g1_sources, "g2": g2_pupils, "g3": g3_mask_spectra, "g4": g4_fields,
          "g5": g5_images, "g6": g6_through_focus, "g8": g8_large_pupils, "g9": g9_config5_stack, "g10": g10_contiguous_shards,
-         "g11": g11_config2_full, "g12": g12_shard4096, "g13": g13_config3_long_run, "g14": g14_config3_rank_shard}[g]()
+         "g11": g11_config2_full, "g12": g12_shard4096, "g13": g13_config3_long_run, "g14": g14_config3_rank_shard, "g15": g15_config5_stack_run}[g]()

@@ -420,6 +420,55 @@ def test_config5_stack_at_size_vs_golden(golden, L, dev, coarse_mode):
             assert rel_max(fused[j], raw[8 + j]) < 1e-6, (pc, j)
 
 
+@pytest.mark.parametrize("path", ["coarse", "direct", "coarse-chunk2"])
+def test_config5_stack_dense_run_vs_golden(golden, L, dev, path):
+    """BASELINE config 5's stack on DENSE reference-made data through many launch batches per plane (golden g15): 8 planes
+    (defocus -310 + 80 j nm) x 240 consecutive source points [90000, 90240) of the 2048^2 quasar list, made by the reference's
+    own loop over Pupil(...) + abbeImage(...).  ONE stacked call: 20 default 12-point batches per plane, plane by plane on the
+    coarse grid (as config 5 runs), on the direct path, and with two planes in flight per launch pair (fused x-pass)."""
+    import os
+    from conftest import GOLDEN
+    from lithographysimulator_amd import _native as nat
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    if not os.path.exists(os.path.join(GOLDEN, "g15_config5_stack_run.npz")):
+        pytest.skip("golden g15 not generated (tests/golden/make_golden.py g15)")
+    g = golden("g15_config5_stack_run.npz")
+    pn = 2048
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    defocus = [float(d) for d in g["defocus_nm"]]
+    stack = L.throughFocusPupils(pn, WL, NA, f16(DEMO_AB), defocus, dev)
+    sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateQuasar(4, -math.pi / 8), pn)
+    lo, hi, S = (int(v) for v in g["range"])
+    assert sh.shape[0] == S
+    sel = sh[lo:hi]
+    assert np.array_equal(sel[[0, -1]].cpu().numpy(), g["first_last_shift"])
+    opts = {"coarse": 0 if path == "direct" else 1}
+    if path == "coarse-chunk2":
+        opts["plane_chunk"] = 2
+    raw = L.abbeIntensity(mft, stack, sel, N, options=opts)
+    plan = nat.last_plan()
+    assert plan["coarse_grid"] == (0 if path == "direct" else 1) and plan["planes_in_flight"] == (2 if path == "coarse-chunk2" else 1), plan
+    assert plan["launches"] == (80 if path == "coarse-chunk2" else 160) and plan["batch"] == 12, plan     # 20 batches x 8 planes
+    img = L.postProcess(raw, eps)
+    assert tuple(img.shape[1:]) == tuple(g["final_shape"])
+    raw, img = raw.cpu(), img.cpu()
+    worst = 0.0
+    for k in range(len(defocus)):
+        for got, kind in ((raw[k], "raw"), (img[k], "final")):
+            mx = float(g[f"{kind}_max"][k])
+            e = max(float((crop_center(got, 64).double() - torch.from_numpy(g[f"{kind}_crop"][k]).double()).abs().max() / mx),
+                    float(np.abs(got[::32, ::32].numpy().astype(np.float64) - g[f"{kind}_stride32"][k]).max() / mx))
+            worst = max(worst, e)
+            assert e < TOL_IMAGE_MAX, (k, kind, e)
+            assert np.allclose(got.double().sum(1).numpy(), g[f"{kind}_rowsum"][k], rtol=2e-5, atol=2e-6 * float(g[f"{kind}_rowsum"][k].max())), (k, kind)
+            assert np.allclose(got.double().sum(0).numpy(), g[f"{kind}_colsum"][k], rtol=2e-5, atol=2e-6 * float(g[f"{kind}_colsum"][k].max())), (k, kind)
+            assert abs(float(got.max()) / mx - 1) < 2e-5 and abs(float(got.double().sum()) / float(g[f"{kind}_sum"][k]) - 1) < 2e-6, (k, kind)
+    print(f"config-5 stack, dense run ({path}): worst pixel error rel-to-max {worst:.2e}")
+    assert rel_max(raw[0], raw[7]) > 1e-3                          # the planes really differ
+
+
 def test_stack_plane_chunk_knob_and_generic_variant(L, dev, monkeypatch):
     _opt(monkeypatch, coarse="0")          # this test is about the kernels of the DIRECT (N = 2 pn) path
     _test_stack_plane_chunk_knob_and_generic_variant(L, dev, monkeypatch)

@@ -243,7 +243,8 @@ def test_shift_one_sample_short_of_wrapping_and_one_past(L, dev, pn, axis, sign)
 
 
 # ------------------------------------------------------------------ mask sizes that are neither N nor N / 2: embedded evaluation
-@pytest.mark.parametrize("pn,ps,pe", [(200, 25, 256), (1000, 25, 1024), (1500, 25, 2048), (768, 25, 1024), (300, 10, 512)])
+@pytest.mark.parametrize("pn,ps,pe", [(200, 25, 256), (1000, 25, 1024), (1500, 25, 2048), (768, 25, 1024), (300, 10, 512), (2000, 25, 2048),
+                                      (3000, 25, 4096)])
 def test_odd_mask_sizes_run_embedded_and_match_the_oracle(L, dev, monkeypatch, pn, ps, pe):
     """A 1000^2 (1500^2, 768^2 ...) mask is neither N nor N / 2: instead of the generic kernels the host side pads mask
     spectrum and pupil into the next such grid, runs the power-of-two kernels (coarse grid included) with the ORIGINAL size
@@ -260,7 +261,7 @@ def test_odd_mask_sizes_run_embedded_and_match_the_oracle(L, dev, monkeypatch, p
     pupil = L.Pupil(pn, WL, NA, f16([0, 0, 0.01, 0, 80, 0.01]), dev).generatePupilFunction()
     bitmap = L.LightSource(0.4, 0.8, pn, NA, device=dev).generateAnnular()
     sh = L.sourceShifts(bitmap, pn)
-    K = 12 if pn <= 1000 else 5
+    K = 12 if pn <= 1000 else 5 if pn <= 1500 else 3
     sel = sh[(torch.arange(K, device=dev) * sh.shape[0]) // K].contiguous()
     ref = o.abbe_raw(mft.cpu(), pupil.cpu(), sel.cpu(), N)
     for coarse in (1, 2, 0):

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LITHO_ABBE_LIB") or os.path.join(_HERE, "lib", "liblitho_abbe.so")
 
-LITHO_OK, E_ARG, E_NSMALL, E_WORKSPACE, E_HIP, E_INDEX, E_WRAP = 0, -1, -2, -3, -4, -5, -6
+LITHO_OK, E_ARG, E_NSMALL, E_WORKSPACE, E_HIP, E_INDEX = 0, -1, -2, -3, -4, -5
 _lib = None
 
 _SIGNATURES = {
@@ -35,8 +35,7 @@ _SIGNATURES = {
                                               c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, POINTER(c_int64)]),
     "litho_abbe_accumulate_opts": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int,
                                            c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, POINTER(c_int64)]),
-    "litho_embed_c64": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
-    "litho_crop_add_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "litho_abbe_embedded_size": (c_int, [c_int, c_int, POINTER(c_int)]),
     "litho_abbe_field": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "litho_postprocess_size": (c_int, [c_int, c_double, POINTER(c_int)]),
     "litho_postprocess": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p]),
@@ -89,9 +88,6 @@ def check(rc, what):
         raise RuntimeError(f"{what}: HIP error: {lib().litho_last_error().decode()}")
     if rc == E_WORKSPACE:
         raise RuntimeError(f"{what}: workspace too small")
-    if rc == E_WRAP:
-        raise RuntimeError(f"{what}: embedded evaluation refused -- a shift wraps the pupil around the original grid "
-                           "(call with the original size; abbeIntensity does that by itself)")
     raise ValueError(f"{what}: unsupported or invalid argument (pn must be even, 2..16384; N a power of two, "
                      "16..16384)")
 
@@ -128,7 +124,6 @@ def ptr(t):
     return c_void_p(t.data_ptr())
 
 
-EMBED_ODD_SIZES = True       # abbeIntensity runs mask sizes other than N and N/2 embedded in the next such grid (imageformation.embeddedSize)
 _workspaces = {}
 WORKSPACE_CACHE_BYTES = 8 << 30      # the cache keeps at most this much per device (one entry always stays)
 
@@ -174,7 +169,7 @@ class PlanRecord(ctypes.Structure):
 class Options(ctypes.Structure):
     """litho_abbe_options (include/litho_abbe.h): per-call launch-planner options; -1 = not set."""
     _names = ("coarse", "batch", "groups", "xchunk", "tile", "plane_chunk", "w64", "rect", "w64_8192", "xsplit", "xrect",
-              "w64x", "gcombine", "rowpairs", "force_generic", "force_general", "poison", "embed_pn")
+              "w64x", "gcombine", "rowpairs", "force_generic", "force_general", "poison", "embed")
     _fields_ = [("size", ctypes.c_int32)] + [(n, ctypes.c_int32) for n in _names]
 
     @classmethod

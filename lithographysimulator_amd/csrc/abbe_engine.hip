@@ -65,7 +65,7 @@ __global__ void k_plan_init(int* plan)
 // Bounding box of the non-zero pupil samples over all planes: grid (row blocks, planes), each block scans
 // BOX_ROWS_PER_BLOCK rows of one plane; one atomic quadruple per block that saw a non-zero.
 static constexpr int BOX_ROWS_PER_BLOCK = 8;
-__global__ __launch_bounds__(256) void k_pupil_box(const float2* __restrict__ P, int pn, int* plan)
+__global__ __launch_bounds__(256) void k_pupil_box(const float2* __restrict__ P, int pn, int* plan, int e_lo, int e_hi)
 {
     __shared__ int red[4][4];
     const int row0 = blockIdx.x * BOX_ROWS_PER_BLOCK;
@@ -78,8 +78,9 @@ __global__ __launch_bounds__(256) void k_pupil_box(const float2* __restrict__ P,
             if (v.x != 0.f || v.y != 0.f) {
                 rmin = min(rmin, row); rmax = max(rmax, row);
                 cmin = min(cmin, j); cmax = max(cmax, j);
-                const int ce = pn / 2, he = pn / 4;          // edges of the natural box: a handful of samples, direct atomics
-                const bool ecol = (j == ce + he || j == ce - he), erow = (row == ce + he || row == ce - he);
+                // edges of the natural box of the grid the engine will RUN at (e_lo, e_hi = c -+ pn/4, or -+ pe/4 of the padded
+                // grid of an embedded evaluation -- then possibly outside this array): a handful of samples, direct atomics
+                const bool ecol = (j == e_hi || j == e_lo), erow = (row == e_hi || row == e_lo);
                 if (ecol) { atomicMin(&plan[9], row); atomicMax(&plan[10], row); }
                 if (erow) { atomicMin(&plan[11], j); atomicMax(&plan[12], j); }
                 if (ecol && erow) atomicExch(&plan[13], 1);
@@ -340,7 +341,29 @@ static size_t ic_bytes(int pn, int N) { return coarse_eligible(pn, N) ? (size_t)
 static size_t chat_bytes(int pn, int N) { return coarse_eligible(pn, N) ? (size_t)pn * pn * sizeof(float2) : 0; }
 static size_t gam_bytes(int pn, int N) { return coarse_eligible(pn, N) ? gam_float2(pn) * sizeof(float2) : 0; }
 
-static size_t workspace_bytes(int pn, int N)
+// Grid size the engine RUNS a pn x pn problem at.  The specialised kernels and the coarse grid
+// exist for pn = N and pn = N / 2; any other even size (a 1000^2 or 3000^2 mask; 10 nm pixels, where N = 4 pn) would fall to
+// the generic, runtime-predicated kernels -- 3.4-3.6x slower per source point than the NEXT LARGER power of two.  Such a
+// problem is embedded instead: mask spectrum and pupil centred in a zero-padded N / 2 (pn < N / 2) or N grid, same shift
+// list, centre pn x pn of the accumulated intensity added to `out` -- the identical sum term by term as long as no shift
+// wraps the pupil around the caller's own grid (checked on the original size; a wrapping list runs the general path as is).
+// Measured (scripts/embed_ab.py, us per source point, embedded / plain): 1000^2 at N 2048 2.48 / 8.38, 2000^2 at N 4096
+// 9.2 / 33.6, 1500^2 at N 2048 7.4 / 16.2, 3000^2 at N 4096 35.2 / 58.8; N = 4 pn: 256^2 0.63 / 0.94, 2048^2 28.4 / 37.7;
+// but 300^2 in a 512 grid 0.52 / 0.50 -- so: N / 2 from 256 up (the coarse grid applies), N from 1024 up.
+static int embedded_size(int pn, int N)
+{
+    if (pn == N || 2 * pn == N || (pn & 1)) return pn;
+    if (2 * pn < N) return N / 2 >= 256 ? N / 2 : pn;
+    return N >= 1024 ? N : pn;
+}
+// scratch of an embedded evaluation behind the workspace of the padded size: mask spectrum, COARSE_PLANES pupils, as many images
+static size_t embed_extra_bytes(int pe)
+{
+    const size_t e = (size_t)pe * pe;
+    return align_up(e * sizeof(float2), 256) + align_up(COARSE_PLANES * e * sizeof(float2), 256) + align_up(COARSE_PLANES * e * sizeof(float), 256);
+}
+
+static size_t workspace_bytes_at(int pn, int N)
 {
     const size_t nt = (pn + 3) / 4;
     size_t b = 256;
@@ -353,10 +376,20 @@ static size_t workspace_bytes(int pn, int N)
     b += align_up(t_budget(pn), 256);
     return b;
 }
+// what litho_abbe_workspace_bytes reports: the engine's own regions at this size, or -- for a size that runs embedded -- the
+// larger of that (the general path of a wrapping source list) and the padded size's regions + the embedding scratch
+static size_t workspace_bytes(int pn, int N)
+{
+    const size_t own = workspace_bytes_at(pn, N);
+    const int pe = embedded_size(pn, N);
+    if (pe == pn) return own;
+    const size_t emb = workspace_bytes_at(pe, N) + embed_extra_bytes(pe);
+    return own > emb ? own : emb;
+}
 
 static bool carve(void* ws, size_t bytes, int pn, int N, Workspace& w)
 {
-    if (!ws || bytes < workspace_bytes(pn, N)) return false;
+    if (!ws || bytes < workspace_bytes_at(pn, N)) return false;
     const size_t nt = (pn + 3) / 4;
     unsigned char* p = (unsigned char*)ws;
     w.plan = (int*)p; p += 256;
@@ -390,7 +423,7 @@ static int env_int(const char* name, int dflt)
 // Tuning / test knobs.  Resolved ONCE per C-ABI call, never per launch: a field of the caller's litho_abbe_options that is
 // >= 0 wins, otherwise the LITHO_ABBE_* environment variable, otherwise the default.
 struct Knobs {
-    int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk, xsplit, rect, xrect, coarse, gcombine, rowpairs, poison, embed_pn;
+    int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk, xsplit, rect, xrect, coarse, gcombine, rowpairs, poison, embed;
     static int pick(const litho_abbe_options* o, size_t off, const char* name, int dflt)
     {
         if (o && off + sizeof(int32_t) <= (size_t)o->size) {
@@ -420,7 +453,7 @@ struct Knobs {
         LITHO_KNOB(gcombine, "LITHO_ABBE_GCOMBINE", 1);
         LITHO_KNOB(rowpairs, "LITHO_ABBE_ROWPAIRS", 0);
         LITHO_KNOB(poison, "LITHO_ABBE_POISON", 0);
-        LITHO_KNOB(embed_pn, "LITHO_ABBE_EMBED_PN", 0);
+        LITHO_KNOB(embed, "LITHO_ABBE_EMBED", 1);
 #undef LITHO_KNOB
         return k;
     }
@@ -829,67 +862,12 @@ static int reconstruct_plane(const SizeOps* ops, const SizeOps* ops_c, const Wor
     return LITHO_OK;
 }
 
-// `reuse`: optional caller-held plan record (litho_abbe_plan).  Valid and matching (pn, N, planes): its words are used, no
-// planning kernel is launched and the call never waits for the stream; otherwise the plan is made as usual and recorded.
-static int abbe_accumulate(const float2* M, const float2* P, int planes, const int* shifts, int64_t S,
-                           const int* count_dev, int64_t* count_out, int pn, int N, float* out, void* ws,
-                           size_t ws_bytes, hipStream_t st, litho_abbe_plan* reuse = nullptr,
-                           const litho_abbe_options* opts = nullptr)
+// Everything after the plan words are known: which kernels run and how the work is batched, the source-point loop, the
+// coarse-grid reconstruction.  `pl` = plan words in THIS grid's coordinates.
+static int accumulate_planned(const float2* M, const float2* P, int planes, const int* shifts, int64_t S, const int pl[PLAN_WORDS],
+                              int pn, int N, float* out, const Workspace& w, const Knobs& kn, const SizeOps* ops, hipStream_t st)
 {
-    int rc = check_sizes(pn, N);
-    if (rc) return rc;
-    if (!M || !P || !out || planes < 1 || S < 0 || (S > 0 && !shifts)) return LITHO_E_ARG;
-    if (count_out) *count_out = 0;
-    if (S == 0) return LITHO_OK;
-    Workspace w;
-    if (!carve(ws, ws_bytes, pn, N, w)) return LITHO_E_WORKSPACE;
-    const SizeOps* ops = size_ops(ilog2(N));
-    if (!ops) return LITHO_E_ARG;
-    if (opts && (opts->size < (int32_t)sizeof(int32_t) || opts->size > 4096)) return LITHO_E_ARG;
-    const Knobs kn = Knobs::read(opts);
-
-    if (kn.poison) {
-        // test knob: every scratch region starts the call as NaN bit patterns -- a kernel that reads scratch it (or an
-        // earlier launch of THIS call) has not written turns the image into NaN (tests/test_gpu_abbe.py)
-        unsigned char* lo = (unsigned char*)w.slab;
-        unsigned char* hi = (unsigned char*)w.T + w.t_bytes;
-        HIP_TRY(hipMemsetAsync(lo, 0xFF, (size_t)(hi - lo), st));
-    }
-    hipLaunchKernelGGL(k_twiddle_table, dim3((N + 255) / 256), dim3(256), 0, st, w.twtab, N);
-    int pl[PLAN_WORDS];
-    const bool from_record = reuse && reuse->valid == 1 && reuse->pn == pn && reuse->N == N && reuse->planes == planes &&
-                             reuse->words[8] <= S;
-    if (from_record) {
-        for (int i = 0; i < PLAN_WORDS; ++i) pl[i] = reuse->words[i];
-    } else {
-        hipLaunchKernelGGL(k_plan_init, dim3(1), dim3(64), 0, st, w.plan);
-        hipLaunchKernelGGL(k_pupil_box, dim3((pn + BOX_ROWS_PER_BLOCK - 1) / BOX_ROWS_PER_BLOCK, planes), dim3(256), 0, st,
-                           P, pn, w.plan);
-        hipLaunchKernelGGL(k_shift_extents, dim3(256), dim3(256), 0, st, shifts, (long long)S, count_dev, w.plan);
-        HIP_TRY(hipGetLastError());
-        rc = read_plan(w, pl, st);                           // the ONE host wait of the image path
-        if (rc) return rc;
-        if (reuse) {
-            for (int i = 0; i < 16; ++i) reuse->words[i] = i < PLAN_WORDS ? pl[i] : 0;
-            reuse->pn = pn; reuse->N = N; reuse->planes = planes; reuse->valid = 1;
-        }
-    }
-    g_last_plan[15] = from_record ? 1 : 0;
-    S = pl[8];                                               // = S, or the device-side count of the source list
-    if (count_out) *count_out = S;
-    if (S == 0 || pl[1] < pl[0]) return LITHO_OK;            // no source point / pupil identically zero: nothing to add
-
-    // Embedded call (options.embed_pn = the caller's real grid size, centred in this pn x pn grid with zero margins: how the
-    // host side runs mask sizes that are not N or N/2 on the power-of-two kernels).  The reference rolls the pupil modulo ITS
-    // grid (imageformation.py:63), so the embedding is exact only while no shifted copy of the pupil support leaves the
-    // ORIGINAL grid; otherwise say so before anything is launched and let the caller take the general path at its own size.
-    if (kn.embed_pn > 0) {
-        if (kn.embed_pn >= pn || ((pn - kn.embed_pn) & 1)) return LITHO_E_ARG;
-        const int off = (pn - kn.embed_pn) / 2, last = kn.embed_pn - 1;
-        const bool inside = pl[0] - off + pl[4] >= 0 && pl[1] - off + pl[5] <= last && pl[2] - off + pl[6] >= 0 && pl[3] - off + pl[7] <= last;
-        if (!inside) return LITHO_E_WRAP;
-    }
-
+    int rc;
     AbbePlan pp;
     rc = plan_abbe(pp, w, kn, pl, pn, N, planes);
     if (rc) return rc;
@@ -966,6 +944,95 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     return LITHO_OK;
 }
 
+void launch_embed_c64(const float2* src, int planes, int pn, float2* dst, int pe, hipStream_t st);     // optics.hip
+void launch_crop_add_f32(const float* src, int planes, int pe, float* dst, int pn, hipStream_t st);
+
+// `reuse`: optional caller-held plan record (litho_abbe_plan).  Valid and matching (pn, N, planes): its words are used, no
+// planning kernel is launched and the call never waits for the stream; otherwise the plan is made as usual and recorded.
+static int abbe_accumulate(const float2* M, const float2* P, int planes, const int* shifts, int64_t S,
+                           const int* count_dev, int64_t* count_out, int pn, int N, float* out, void* ws,
+                           size_t ws_bytes, hipStream_t st, litho_abbe_plan* reuse = nullptr,
+                           const litho_abbe_options* opts = nullptr)
+{
+    int rc = check_sizes(pn, N);
+    if (rc) return rc;
+    if (!M || !P || !out || planes < 1 || S < 0 || (S > 0 && !shifts)) return LITHO_E_ARG;
+    if (count_out) *count_out = 0;
+    if (S == 0) return LITHO_OK;
+    Workspace w;
+    if (!carve(ws, ws_bytes, pn, N, w)) return LITHO_E_WORKSPACE;
+    const SizeOps* ops = size_ops(ilog2(N));
+    if (!ops) return LITHO_E_ARG;
+    if (opts && (opts->size < (int32_t)sizeof(int32_t) || opts->size > 4096)) return LITHO_E_ARG;
+    const Knobs kn = Knobs::read(opts);
+    // the grid this problem runs at: its own, or the padded one of an embedded evaluation (embedded_size) when the workspace
+    // has room for it (litho_abbe_workspace_bytes says so; an older, smaller workspace simply runs the problem as it is)
+    int pe = kn.embed ? embedded_size(pn, N) : pn;
+    if (pe != pn && ws_bytes < workspace_bytes_at(pe, N) + embed_extra_bytes(pe)) pe = pn;
+
+    if (kn.poison) {
+        // test knob: every scratch region starts the call as NaN bit patterns -- a kernel that reads scratch it (or an
+        // earlier launch of THIS call) has not written turns the image into NaN (tests/test_gpu_abbe.py)
+        unsigned char* lo = (unsigned char*)ws + 256 + align_up((size_t)N * sizeof(float2), 256);       // behind plan words + twiddle table
+        unsigned char* hi = pe != pn ? (unsigned char*)ws + workspace_bytes_at(pe, N) + embed_extra_bytes(pe) : (unsigned char*)w.T + w.t_bytes;
+        if ((unsigned char*)w.T + w.t_bytes > hi) hi = (unsigned char*)w.T + w.t_bytes;
+        HIP_TRY(hipMemsetAsync(lo, 0xFF, (size_t)(hi - lo), st));
+    }
+    hipLaunchKernelGGL(k_twiddle_table, dim3((N + 255) / 256), dim3(256), 0, st, w.twtab, N);
+    int pl[PLAN_WORDS];
+    const bool from_record = reuse && reuse->valid == 1 && reuse->pn == pn && reuse->N == N && reuse->planes == planes &&
+                             reuse->words[8] <= S;
+    if (from_record) {
+        for (int i = 0; i < PLAN_WORDS; ++i) pl[i] = reuse->words[i];
+    } else {
+        hipLaunchKernelGGL(k_plan_init, dim3(1), dim3(64), 0, st, w.plan);
+        hipLaunchKernelGGL(k_pupil_box, dim3((pn + BOX_ROWS_PER_BLOCK - 1) / BOX_ROWS_PER_BLOCK, planes), dim3(256), 0, st,
+                           P, pn, w.plan, pn / 2 - pe / 4, pn / 2 + pe / 4);
+        hipLaunchKernelGGL(k_shift_extents, dim3(256), dim3(256), 0, st, shifts, (long long)S, count_dev, w.plan);
+        HIP_TRY(hipGetLastError());
+        rc = read_plan(w, pl, st);                           // the ONE host wait of the image path
+        if (rc) return rc;
+        if (reuse) {
+            for (int i = 0; i < 16; ++i) reuse->words[i] = i < PLAN_WORDS ? pl[i] : 0;
+            reuse->pn = pn; reuse->N = N; reuse->planes = planes; reuse->valid = 1;
+        }
+    }
+    g_last_plan[15] = from_record ? 1 : 0;
+    S = pl[8];                                               // = S, or the device-side count of the source list
+    if (count_out) *count_out = S;
+    if (S == 0 || pl[1] < pl[0]) return LITHO_OK;            // no source point / pupil identically zero: nothing to add
+
+    // Embedded evaluation -- unless a shift wraps the pupil around the CALLER's grid: the reference rolls modulo its own size
+    // (imageformation.py:63), which the padded grid would not reproduce; such a list runs the general path at this size.
+    const bool nowrap = pl[0] + pl[4] >= 0 && pl[1] + pl[5] <= pn - 1 && pl[2] + pl[6] >= 0 && pl[3] + pl[7] <= pn - 1;
+    if (pe == pn || !nowrap || kn.force_general) return accumulate_planned(M, P, planes, shifts, S, pl, pn, N, out, w, kn, ops, st);
+
+    Workspace w2;
+    if (!carve(ws, ws_bytes, pe, N, w2)) return LITHO_E_WORKSPACE;          // (cannot fail: checked above)
+    unsigned char* extra = (unsigned char*)ws + workspace_bytes_at(pe, N);
+    const size_t e2 = (size_t)pe * pe;
+    float2* M2 = (float2*)extra;
+    float2* P2 = (float2*)(extra + align_up(e2 * sizeof(float2), 256));
+    float* O2 = (float*)((unsigned char*)P2 + align_up(COARSE_PLANES * e2 * sizeof(float2), 256));
+    const int off = (pe - pn) / 2;
+    int pl2[PLAN_WORDS];
+    for (int i = 0; i < PLAN_WORDS; ++i) pl2[i] = pl[i];
+    for (int i = 0; i < 4; ++i) pl2[i] += off;                                // the pupil's support box, in the padded grid
+    if (pl[10] >= pl[9]) { pl2[9] += off; pl2[10] += off; }                   // its samples on the padded grid's natural-box edges
+    if (pl[12] >= pl[11]) { pl2[11] += off; pl2[12] += off; }
+    launch_embed_c64(M, 1, pn, M2, pe, st);
+    for (int p0 = 0; p0 < planes; p0 += COARSE_PLANES) {
+        const int pc = planes - p0 < COARSE_PLANES ? planes - p0 : COARSE_PLANES;
+        launch_embed_c64(P + (size_t)p0 * pn * pn, pc, pn, P2, pe, st);
+        HIP_TRY(zero_async(O2, (size_t)pc * e2 * sizeof(float), st));
+        rc = accumulate_planned(M2, P2, pc, shifts, S, pl2, pe, N, O2, w2, kn, ops, st);
+        if (rc) return rc;
+        launch_crop_add_f32(O2, pc, pe, out + (size_t)p0 * pn * pn, pn, st);
+        HIP_TRY(hipGetLastError());
+    }
+    return LITHO_OK;
+}
+
 static int abbe_field(const float2* pf, const float2* M, int pn, int N, float2* field, void* ws, size_t ws_bytes,
                       hipStream_t st)
 {
@@ -976,7 +1043,8 @@ static int abbe_field(const float2* pf, const float2* M, int pn, int N, float2* 
     if (!carve(ws, ws_bytes, pn, N, w)) return LITHO_E_WORKSPACE;
     hipLaunchKernelGGL(k_twiddle_table, dim3((N + 255) / 256), dim3(256), 0, st, w.twtab, N);
     hipLaunchKernelGGL(k_plan_init, dim3(1), dim3(64), 0, st, w.plan);
-    hipLaunchKernelGGL(k_pupil_box, dim3((pn + BOX_ROWS_PER_BLOCK - 1) / BOX_ROWS_PER_BLOCK, 1), dim3(256), 0, st, pf, pn, w.plan);
+    hipLaunchKernelGGL(k_pupil_box, dim3((pn + BOX_ROWS_PER_BLOCK - 1) / BOX_ROWS_PER_BLOCK, 1), dim3(256), 0, st, pf, pn, w.plan,
+                       pn / 2 - pn / 4, pn / 2 + pn / 4);
     HIP_TRY(hipGetLastError());
     int pl[PLAN_WORDS];
     rc = read_plan(w, pl, st);
@@ -1050,6 +1118,15 @@ int litho_abbe_workspace_bytes(int pn, int N, size_t* bytes_host)
     int rc = litho::check_sizes(pn, N);
     if (rc) return rc;
     *bytes_host = litho::workspace_bytes(pn, N);
+    return LITHO_OK;
+}
+
+int litho_abbe_embedded_size(int pn, int N, int* size_host)
+{
+    if (!size_host) return LITHO_E_ARG;
+    int rc = litho::check_sizes(pn, N);
+    if (rc) return rc;
+    *size_host = litho::embedded_size(pn, N);
     return LITHO_OK;
 }
 

@@ -301,6 +301,14 @@ __global__ __launch_bounds__(256) void k_crop_add_f32(const float* __restrict__ 
     const int o = (pe - pn) / 2;
     dst[((size_t)blockIdx.z * pn + y) * pn + x] += src[((size_t)blockIdx.z * pe + y + o) * pe + x + o];
 }
+void launch_embed_c64(const float2* src, int planes, int pn, float2* dst, int pe, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_embed_c64, dim3((pe + 255) / 256, pe, planes), dim3(256), 0, st, src, pn, dst, pe);
+}
+void launch_crop_add_f32(const float* src, int planes, int pe, float* dst, int pn, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_crop_add_f32, dim3((pn + 255) / 256, pn, planes), dim3(256), 0, st, src, pe, dst, pn);
+}
 
 }  // namespace litho
 
@@ -453,25 +461,6 @@ int litho_postprocess(const float* raw, int planes, int pn, double epsilon, floa
     const float rs = (float)(1.0 / scale);
     hipLaunchKernelGGL(k_postprocess<false>, dim3((n_out + 255) / 256, n_out, planes), dim3(256), 0, (hipStream_t)stream,
                        raw, pn, ns, pW, n_out, rs, out, 1.0f, 0.0f, (unsigned char*)nullptr);
-    HIP_TRY(hipGetLastError());
-    return LITHO_OK;
-}
-
-int litho_embed_c64(const void* src, int planes, int pn, void* dst, int pe, void* stream)
-{
-    using namespace litho;
-    if (!src || !dst || planes < 1 || pn < 1 || pe < pn || ((pe - pn) & 1)) return LITHO_E_ARG;
-    hipLaunchKernelGGL(k_embed_c64, dim3((pe + 255) / 256, pe, planes), dim3(256), 0, (hipStream_t)stream, (const float2*)src, pn,
-                       (float2*)dst, pe);
-    HIP_TRY(hipGetLastError());
-    return LITHO_OK;
-}
-
-int litho_crop_add_f32(const float* src, int planes, int pe, float* dst, int pn, void* stream)
-{
-    using namespace litho;
-    if (!src || !dst || planes < 1 || pn < 1 || pe < pn || ((pe - pn) & 1)) return LITHO_E_ARG;
-    hipLaunchKernelGGL(k_crop_add_f32, dim3((pn + 255) / 256, pn, planes), dim3(256), 0, (hipStream_t)stream, src, pe, dst, pn);
     HIP_TRY(hipGetLastError());
     return LITHO_OK;
 }

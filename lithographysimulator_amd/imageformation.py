@@ -70,11 +70,10 @@ class PlanCache:
         self.workspace = None       # engine scratch of the planned calls (kept alive for captured graphs)
         self.identity = None        # what the record was made for (see _identity): abbeIntensity's pupil + shift list
         self.image_identity = None  # ... and abbeImage's pupil + source bitmap
-        self.padded_pupil = None    # embedded evaluation (mask sizes other than N, N / 2): the zero-padded pupil (stack)
 
     def invalidate(self):
         self.record.valid = 0
-        self.shifts = self.count = self.S = self.identity = self.image_identity = self.padded_pupil = None
+        self.shifts = self.count = self.S = self.identity = self.image_identity = None
 
     @property
     def valid(self):
@@ -87,20 +86,14 @@ def _identity(*tensors):
 
 
 def embeddedSize(pn: int, N: int) -> int:
-    """Grid size the engine runs a pn x pn problem at.  The specialised kernels (and the coarse grid) exist for pn = N and
-    pn = N / 2, N a power of two; any other even size -- a 1000^2 or 3000^2 mask -- would fall to the generic,
-    runtime-predicated kernels (measured 3.4-3.6x slower per source point than the NEXT LARGER power of two).  Such a problem
-    is embedded instead: mask spectrum and pupil centred in a zero-padded N/2 (pn < N/2) or N grid, the same shift list, the
-    centre pn x pn of the accumulated intensity cropped out -- the identical sum, term by term, as long as no shift wraps the
-    pupil around the caller's own grid (the engine checks that on the original size and refuses otherwise)."""
-    if pn == N or 2 * pn == N or (pn & 1):
-        return pn
-    # Measured (scripts/embed_ab.py, us per source point, embedded / plain): 1000^2 at N 2048 2.48 / 8.38, 2000^2 at N 4096
-    # 9.2 / 33.6, 1500^2 at N 2048 7.4 / 16.2, 3000^2 at N 4096 35.2 / 58.8, 2000^2 at N 2048 8.6 / 29.1; N = 4 pn (10 nm
-    # pixels): 256^2 0.63 / 0.94, 1024^2 5.9 / 6.2, 2048^2 28.4 / 37.7; but 300^2 in a 512 grid 0.52 / 0.50.
-    if 2 * pn < N:
-        return N // 2 if N // 2 >= 256 else pn         # N / 2: the coarse grid applies
-    return N if N >= 1024 else pn                      # N: the full-output kernels; below 1024 the padding does not pay
+    """Grid size the engine RUNS a pn x pn problem at (litho_abbe_embedded_size).  The specialised kernels (and the coarse grid)
+    exist for pn = N and pn = N / 2; any other even size -- a 1000^2 or 3000^2 mask; 10 nm pixels, where N = 4 pn -- is
+    evaluated embedded, inside the library: mask spectrum and pupil centred in a zero-padded N / 2 or N grid, the same shift
+    list, the centre of the accumulated intensity added to the caller's image.  Identical sum, 1.7-3.6x faster than the generic
+    kernels such sizes used to run on; options {"embed": 0} turns it off."""
+    size = ctypes.c_int(0)
+    nat.check(nat.lib().litho_abbe_embedded_size(int(pn), int(N), ctypes.byref(size)), "litho_abbe_embedded_size")
+    return size.value
 
 
 def _plan_workspace(plan, dev, pn, N, pupilF, shifts):
@@ -118,41 +111,6 @@ def _plan_workspace(plan, dev, pn, N, pupilF, shifts):
     return plan.workspace
 
 
-def _embedded_intensity(m, p, sh, count, plan, options, pn, pe, N, out, stacked, planes, dev, pupilF, shifts):
-    """abbeIntensity of a pn x pn problem on the pe x pe grid (embeddedSize): pad, one C call with options.embed_pn = pn,
-    crop.  Returns what abbeIntensity returns, or None when the engine reports LITHO_E_WRAP (nothing accumulated)."""
-    lib, st = nat.lib(), nat.stream_ptr(dev)
-    m2 = torch.empty((pe, pe), dtype=torch.complex64, device=dev)
-    acc = torch.zeros((planes, pe, pe), dtype=torch.float32, device=dev)
-    ws = _plan_workspace(plan, dev, pe, N, pupilF, shifts)
-    # the padded pupil (stack) of a planned sequence is made once: same pupil tensor (identity checked above), same padding
-    p2 = plan.padded_pupil if (plan is not None and plan.valid and plan.padded_pupil is not None
-                               and tuple(plan.padded_pupil.shape) == (planes, pe, pe)) else None
-    with torch.cuda.device(dev):
-        nat.check(lib.litho_embed_c64(nat.ptr(m), 1, pn, nat.ptr(m2), pe, st), "litho_embed_c64")
-        if p2 is None:
-            p2 = torch.empty((planes, pe, pe), dtype=torch.complex64, device=dev)
-            nat.check(lib.litho_embed_c64(nat.ptr(p), planes, pn, nat.ptr(p2), pe, st), "litho_embed_c64")
-            if plan is not None:
-                plan.padded_pupil = p2
-    opts = nat.current_options(dict(options or {}, embed_pn=pn))
-    S = ctypes.c_int64(0)
-    with torch.cuda.device(dev):
-        rc = nat.lib().litho_abbe_accumulate_opts(nat.ptr(m2), nat.ptr(p2), planes, nat.ptr(sh),
-                                                  nat.ptr(count) if count is not None else None, sh.shape[0], pe, N,
-                                                  nat.ptr(acc), nat.ptr(ws), ws.numel(), nat.stream_ptr(dev),
-                                                  ctypes.byref(plan.record) if plan is not None else None,
-                                                  ctypes.byref(opts), ctypes.byref(S))
-    if rc == nat.E_WRAP:
-        if plan is not None:
-            plan.record.valid = 0                      # the record was made for the padded grid
-        return None
-    nat.check(rc, "litho_abbe_accumulate_opts")
-    with torch.cuda.device(dev):
-        nat.check(lib.litho_crop_add_f32(nat.ptr(acc), planes, pe, nat.ptr(out), pn, st), "litho_crop_add_f32")
-    return (out, S.value) if (plan is not None or count is not None) else out
-
-
 def abbeIntensity(maskFT, pupilF, shifts, N, out=None, count=None, plan=None, options=None):
     """The loop of abbeImage (imageformation.py:54-67) for an explicit (dy,dx) list:
     returns / accumulates into the raw fp32 intensity [planes?,pn,pn] BEFORE post-processing.
@@ -162,7 +120,7 @@ def abbeIntensity(maskFT, pupilF, shifts, N, out=None, count=None, plan=None, op
     stream once.  `plan`: optional PlanCache (see there); the call then returns (intensity, S) as well.
     `options`: optional mapping of launch-planner options for THIS call (litho_abbe_options: coarse, batch, groups,
     xchunk, tile, plane_chunk, ...; see _native.engineOptions), merged over the enclosing engineOptions blocks.
-    Mask sizes other than N and N / 2 run embedded in the next such grid (embeddedSize)."""
+    Mask sizes other than N and N / 2 run embedded in the next such grid, inside the library (embeddedSize)."""
     pn = _square(maskFT, "maskFT")
     if pupilF.dim() not in (2, 3) or tuple(pupilF.shape[-2:]) != (pn, pn) or (pupilF.dim() == 3 and pupilF.shape[0] < 1):
         # e.g. a default Pupil() (pixelNumber 64) with a 256^2 mask: the reference fails at pf * maskFFFT
@@ -187,11 +145,6 @@ def abbeIntensity(maskFT, pupilF, shifts, N, out=None, count=None, plan=None, op
     nat.check(rc, "abbeImage")
     if count is not None and (count.dtype != torch.int32 or count.numel() != 1 or count.device != m.device):
         raise ShapeError("count must be a 1-element int32 tensor on the mask's device")
-    pe = embeddedSize(pn, int(N))
-    if pe != pn and nat.EMBED_ODD_SIZES:
-        done = _embedded_intensity(m, p, sh, count, plan, options, pn, pe, int(N), out, stacked, planes, dev, pupilF, shifts)
-        if done is not None:
-            return done                                # (None: a shift wraps the pupil around the caller's grid -- general path below)
     ws = _plan_workspace(plan, dev, pn, int(N), pupilF, shifts)
     opts = nat.current_options(options)
     with torch.cuda.device(dev):
@@ -347,9 +300,7 @@ def abbeImage(mask, maskFT: torch.Tensor, pupilF: torch.Tensor, lightsource: tor
         planes = pupilF.shape[0] if pupilF.dim() == 3 else 1
         r = plan_cache.record
         ident = _identity(pupilF, lightsource)
-        # (the record is made at the size the engine ran at: the caller's, or the padded grid of an embedded evaluation)
-        if (plan_cache.shifts is None or not plan_cache.valid or r.pn not in (pixelNumber, embeddedSize(pixelNumber, int(N)))
-                or (r.N, r.planes) != (int(N), planes)
+        if (plan_cache.shifts is None or not plan_cache.valid or (r.pn, r.N, r.planes) != (pixelNumber, int(N), planes)
                 or plan_cache.image_identity != ident):
             plan_cache.invalidate()
             plan_cache.image_identity = ident

@@ -16,13 +16,13 @@ for arg in sys.argv[1:]:
     sel = sh[sh.shape[0] // 3: sh.shape[0] // 3 + k].contiguous()
     res = {}
     for emb in (True, False, True, False):
-        nat.EMBED_ODD_SIZES = emb
-        L.abbeIntensity(mft, pf, sel, N)
+        o = {"embed": int(emb)}
+        L.abbeIntensity(mft, pf, sel, N, options=o)
         best = 1e30
         for _ in range(3):
             torch.cuda.synchronize()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(); L.abbeIntensity(mft, pf, sel, N); b.record(); torch.cuda.synchronize()
+            a.record(); L.abbeIntensity(mft, pf, sel, N, options=o); b.record(); torch.cuda.synchronize()
             best = min(best, a.elapsed_time(b))
         p = nat.last_plan()
         res[emb] = min(res.get(emb, 1e30), best * 1e3 / k)

@@ -156,9 +156,9 @@ def test_other_fft_ratios_vs_golden(golden, L, dev, ps):
 def test_other_fft_ratios_mid_size_vs_oracle(L, dev, monkeypatch, pn, ps, embed):
     """N = pn (pixelSize 48: the RL = 0 pruned kernels, 9 live input slots) and N = 4 pn (pixelSize 10: RL = 2) at
     sizes where a line spans whole workgroups, against the CPU oracle's op chain and its post-process.  N = 4 pn twice: on
-    the RL = 2 kernels (host-side embedding off) and as a caller gets it since round 4 (embedded in the N / 2 grid: RL = 1)."""
+    the RL = 2 kernels (embedding off) and as a caller gets it since round 4 (embedded in the N / 2 grid: RL = 1)."""
     from lithographysimulator_amd import _native as nat
-    monkeypatch.setattr(nat, "EMBED_ODD_SIZES", embed)
+    _opt(monkeypatch, embed=int(embed))
     from lithographysimulator_amd.synthetic import bernoulli_mask
     o = O()
     mask = L.Mask(bernoulli_mask(pn), ps, dev)

@@ -246,9 +246,9 @@ def test_shift_one_sample_short_of_wrapping_and_one_past(L, dev, pn, axis, sign)
 @pytest.mark.parametrize("pn,ps,pe", [(200, 25, 256), (1000, 25, 1024), (1500, 25, 2048), (768, 25, 1024), (300, 10, 512), (2000, 25, 2048),
                                       (3000, 25, 4096)])
 def test_odd_mask_sizes_run_embedded_and_match_the_oracle(L, dev, monkeypatch, pn, ps, pe):
-    """A 1000^2 (1500^2, 768^2 ...) mask is neither N nor N / 2: instead of the generic kernels the host side pads mask
-    spectrum and pupil into the next such grid, runs the power-of-two kernels (coarse grid included) with the ORIGINAL size
-    as options.embed_pn, and crops.  Same sum term by term: single plane, a stack, a pre-filled `out`, through abbeImage, with
+    """A 1000^2 (1500^2, 768^2 ...) mask is neither N nor N / 2: instead of the generic kernels the library pads mask
+    spectrum and pupil into the next such grid inside its workspace, runs the power-of-two kernels (coarse grid included)
+    and adds the centre of the padded image to the caller's.  Same sum term by term: single plane, a stack, a pre-filled `out`, through abbeImage, with
     a PlanCache -- against the oracle and against the un-embedded generic evaluation."""
     o = O()
     from lithographysimulator_amd.synthetic import bernoulli_mask
@@ -270,10 +270,8 @@ def test_odd_mask_sizes_run_embedded_and_match_the_oracle(L, dev, monkeypatch, p
         assert plan["general"] == 0 and plan["variant"] >= 0, plan               # a specialised kernel family, at the padded size
         assert plan["coarse_grid"] == (1 if coarse == 2 and 2 * pe == N else 0), (coarse, plan)
         _check(got, ref, f"{pn}^2 (N {N}) embedded in {pe}^2, coarse={coarse}, kernels {nat().last_kernels()}")
-    monkeypatch.setattr(nat(), "EMBED_ODD_SIZES", False)
-    plain = L.abbeIntensity(mft, pupil, sel, N).cpu()
+    plain = L.abbeIntensity(mft, pupil, sel, N, options={"embed": 0}).cpu()
     assert nat().last_plan()["variant"] == (-1 if pn & (pn - 1) else nat().last_plan()["variant"])
-    monkeypatch.setattr(nat(), "EMBED_ODD_SIZES", True)
     _check(plain, ref, f"{pn}^2 un-embedded")
     # a stack, accumulated into a pre-filled buffer
     stack = L.throughFocusPupils(pn, WL, NA, f16([0, 0, 0.01, 0, 80, 0.01]), [-60.0, 40.0], dev)
@@ -289,7 +287,7 @@ def test_odd_mask_sizes_run_embedded_and_match_the_oracle(L, dev, monkeypatch, p
     cache = L.PlanCache()
     img1 = L.abbeImage(mask, mft, pupil, few, ps, mask.deltaK, WL, True, dev, plan_cache=cache)
     img2 = L.abbeImage(mask, mft, pupil, few, ps, mask.deltaK, WL, True, dev, plan_cache=cache)
-    assert nat().last_plan()["planned_from_record"] == 1 and cache.record.pn == pe and torch.equal(img1, img2)
+    assert nat().last_plan()["planned_from_record"] == 1 and cache.record.pn == pn and torch.equal(img1, img2)
     want = o.post_process(o.abbe_raw(mft.cpu(), pupil.cpu(), o.source_shifts(few.cpu(), pn), N), eps)
     assert img1.shape == want.shape
     _check(img1.cpu(), want, f"{pn}^2 abbeImage end to end")
@@ -302,8 +300,8 @@ def test_odd_mask_sizes_run_embedded_and_match_the_oracle(L, dev, monkeypatch, p
 @pytest.mark.parametrize("pn", [200, 1000])
 def test_embedded_evaluation_refuses_shifts_that_wrap_the_original_grid(L, dev, pn):
     """The reference rolls the pupil modulo ITS grid (imageformation.py:63).  In the padded grid a large shift has room
-    that the original grid does not: the engine tests the wrap on the ORIGINAL size (LITHO_E_WRAP, nothing accumulated) and
-    the host side falls back to the general path at the caller's size -- one sample short of wrapping runs embedded."""
+    that the original grid does not: the engine tests the wrap on the ORIGINAL size and runs such a list on the general path
+    at the caller's size -- one sample short of wrapping runs embedded."""
     o = O()
     gen = torch.Generator().manual_seed(3 * pn)
     mask = L.Mask((torch.rand(pn, pn, generator=gen) < 0.5).to(torch.int16), PS, dev)

@@ -102,15 +102,17 @@ def test_osa_indices_and_pupil_defaults(capsys):
 
 
 def test_embedded_size_rule():
-    """Which grid a pn x pn problem runs at (imageformation.embeddedSize): N and N / 2 as they are, everything else even in the
-    next of the two -- N / 2 from 256 up (the coarse grid applies), N from 1024 up -- odd sizes untouched (rejected later)."""
+    """Which grid a pn x pn problem runs at (litho_abbe_embedded_size, host-only): N and N / 2 as they are, everything else even
+    in the next of the two -- N / 2 from 256 up (the coarse grid applies), N from 1024 up."""
     table = {(1024, 2048): 1024, (2048, 2048): 2048, (1000, 2048): 1024, (1500, 2048): 2048, (2000, 4096): 2048, (3000, 4096): 4096,
              (768, 1024): 1024, (200, 512): 256, (300, 512): 300, (300, 1024): 512, (96, 128): 96, (100, 256): 100,
-             (1024, 4096): 2048, (256, 1024): 512, (64, 256): 64, (2000, 2048): 2048, (1001, 2048): 1001, (8192, 16384): 8192}
+             (1024, 4096): 2048, (256, 1024): 512, (64, 256): 64, (2000, 2048): 2048, (8192, 16384): 8192}
     for (pn, N), want in table.items():
         assert L.embeddedSize(pn, N) == want, (pn, N)
         pe = L.embeddedSize(pn, N)
         assert pe == pn or ((pe - pn) % 2 == 0 and pe in (N, N // 2) and pe > pn)
+    with pytest.raises(ValueError):
+        L.embeddedSize(1001, 2048)                     # odd sizes are not served at all (DESIGN.md section 9)
 
 
 def test_synthetic_masks_are_reproducible():

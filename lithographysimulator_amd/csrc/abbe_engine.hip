@@ -980,8 +980,10 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     }
     hipLaunchKernelGGL(k_twiddle_table, dim3((N + 255) / 256), dim3(256), 0, st, w.twtab, N);
     int pl[PLAN_WORDS];
+    // (record word 14 = the grid the edge words were looked up for: a record made with the embedding off, or with a smaller
+    // workspace, is not reused for an embedded run and vice versa)
     const bool from_record = reuse && reuse->valid == 1 && reuse->pn == pn && reuse->N == N && reuse->planes == planes &&
-                             reuse->words[8] <= S;
+                             reuse->words[8] <= S && reuse->words[14] == pe;
     if (from_record) {
         for (int i = 0; i < PLAN_WORDS; ++i) pl[i] = reuse->words[i];
     } else {
@@ -994,6 +996,7 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
         if (rc) return rc;
         if (reuse) {
             for (int i = 0; i < 16; ++i) reuse->words[i] = i < PLAN_WORDS ? pl[i] : 0;
+            reuse->words[14] = pe;
             reuse->pn = pn; reuse->N = N; reuse->planes = planes; reuse->valid = 1;
         }
     }

@@ -291,6 +291,13 @@ def test_odd_mask_sizes_run_embedded_and_match_the_oracle(L, dev, monkeypatch, p
     want = o.post_process(o.abbe_raw(mft.cpu(), pupil.cpu(), o.source_shifts(few.cpu(), pn), N), eps)
     assert img1.shape == want.shape
     _check(img1.cpu(), want, f"{pn}^2 abbeImage end to end")
+    # a record made for the embedded run is not reused with the embedding off (its edge words were looked up for the padded
+    # grid), and the other way round
+    img_off = L.abbeImage(mask, mft, pupil, few, ps, mask.deltaK, WL, True, dev, plan_cache=cache, options={"embed": 0})
+    assert nat().last_plan()["planned_from_record"] == 0
+    _check(img_off.cpu(), want, f"{pn}^2 abbeImage, same PlanCache, embedding off")
+    L.abbeImage(mask, mft, pupil, few, ps, mask.deltaK, WL, True, dev, plan_cache=cache)
+    assert nat().last_plan()["planned_from_record"] == 0
     img3 = L.abbeImage(mask, mft, pupil, few, ps, mask.deltaK, WL, True, dev)            # the default call: device-side source count
     assert nat().last_plan()["planned_from_record"] == 0 and torch.equal(img3, img1)
     norm = L.abbeImage(mask, mft, pupil, few, ps, mask.deltaK, WL, True, dev, normalize=True)

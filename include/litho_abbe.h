@@ -124,7 +124,8 @@ int litho_abbe_accumulate_counted(const void *maskFT, const void *pupil, int pla
  * and planes are checked.  count_dev may be NULL (then `capacity` is the number of source points, as in
  * litho_abbe_accumulate).  litho_abbe_last_plan field [15] = 1 when the call planned from the record. */
 typedef struct litho_abbe_plan {
-    int32_t words[16];      /* the read-back plan words (the library's business; [8] = source-point count) */
+    int32_t words[16];      /* the read-back plan words (the library's business; [8] = source-point count, [14] = the grid
+                             * size the run was planned for: the call's own or the padded one of an embedded evaluation) */
     int32_t valid;          /* 0: empty, the call fills it; 1: use it */
     int32_t pn, N, planes;  /* what it was made for */
 } litho_abbe_plan;

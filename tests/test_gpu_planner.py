@@ -243,7 +243,7 @@ def test_shift_one_sample_short_of_wrapping_and_one_past(L, dev, pn, axis, sign)
 
 
 # ------------------------------------------------------------------ mask sizes that are neither N nor N / 2: embedded evaluation
-@pytest.mark.parametrize("pn,ps,pe", [(200, 25, 256), (1000, 25, 1024), (1500, 25, 2048), (768, 25, 1024), (300, 10, 512), (2000, 25, 2048),
+@pytest.mark.parametrize("pn,ps,pe", [(200, 25, 256), (1000, 25, 1024), (1500, 25, 2048), (768, 25, 1024), (300, 10, 512), (502, 25, 512), (2000, 25, 2048),
                                       (3000, 25, 4096)])
 def test_odd_mask_sizes_run_embedded_and_match_the_oracle(L, dev, monkeypatch, pn, ps, pe):
     """A 1000^2 (1500^2, 768^2 ...) mask is neither N nor N / 2: instead of the generic kernels the library pads mask

@@ -280,6 +280,12 @@ def test_odd_mask_sizes_run_embedded_and_match_the_oracle(L, dev, monkeypatch, p
     for k in range(2):
         want = pre[k].cpu().double() + o.abbe_raw(mft.cpu(), stack[k].cpu(), sel.cpu(), N).double()
         _check(both[k], want, f"{pn}^2 stack plane {k}, pre-filled out")
+    if pn == 200:
+        # more planes than the embedding pads at once (four): chunk boundaries of the padded stack
+        st6 = L.throughFocusPupils(pn, WL, NA, f16([0, 0, 0.01, 0, 80, 0.01]), [-100.0, -60.0, -20.0, 20.0, 60.0, 100.0], dev)
+        six = L.abbeIntensity(mft, st6, sel, N, options={"coarse": 2}).cpu()
+        for k in range(6):
+            _check(six[k], o.abbe_raw(mft.cpu(), st6[k].cpu(), sel.cpu(), N), f"{pn}^2 six-plane stack, plane {k}")
     # end to end, with a PlanCache (second call plans from the record, on the padded grid)
     few = torch.zeros_like(bitmap)
     pts = torch.argwhere(bitmap)[(torch.arange(K, device=dev) * sh.shape[0]) // K]

@@ -45,7 +45,13 @@ $(OUT): build/abbe_engine.o build/optics.o build/layout.o build/common.o $(INST)
 oracle:
 	$(MAKE) -C oracle
 
+# the C ABI driven from plain C (no Python, no torch): the reference's demo configuration; build/c_abi_demo [pn]
+examples: build/c_abi_demo
+build/c_abi_demo: examples/c_abi_demo.c include/litho_abbe.h $(OUT)
+	@mkdir -p build
+	gcc -std=c99 -Wall -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude $< -Llithographysimulator_amd/lib -llitho_abbe -L/opt/rocm/lib -lamdhip64 -lm -o $@
+
 clean:
 	rm -rf build $(OUT)
 	$(MAKE) -C oracle clean
-.PHONY: all oracle clean
+.PHONY: all oracle clean examples

@@ -561,6 +561,53 @@ def g15_config5_stack_run():
     save("g15_config5_stack_run.npz", **out)
 
 
+def odd_mask(pn):
+    """Deterministic 0/1 mask for sizes that are not multiples of 64 (integer hash, as synthetic.bernoulli_mask)."""
+    return bernoulli_mask(pn)
+
+
+def g16_odd_sizes():
+    """Mask sizes that are NOT powers of two, by the reference itself (its torch.fft path takes any size): 200^2 (N 512),
+    1000^2 (N 2048), 1500^2 (N 2048) with the demo pupil and annular 0.4-0.8 sources -- K strided points each, plus 600
+    CONSECUTIVE points at 1000^2 (a source list long enough for the engine's coarse grid at the padded size).  The engine runs
+    these embedded in 256^2 / 1024^2 / 2048^2 grids; the reference knows nothing of that."""
+    print("G16 odd mask sizes")
+    out = {}
+    for tag, pn, K in (("p200", 200, 24), ("p1000", 1000, 12), ("p1500", 1500, 6)):
+        mk = quiet(ref_mask.Mask, odd_mask(pn), PS, CPU)
+        mft = mk.fraunhofer(WL, True)
+        eps, N = mk.calculateEpsilonN(mk.deltaK, PS, WL)
+        full = source("annular", pn, 0.4, 0.8)
+        bm = subsample_bitmap(full, K)
+        pf = pupil_fn(pn, DEMO_AB)
+        final, raw = full_image_with_raw(mk, mft, pf, bm)
+        out[f"{tag}_N"] = np.int64(N)
+        out[f"{tag}_S_full"] = np.int64(full.sum())
+        out[f"{tag}_shifts"] = shifts_of(bm, pn)
+        for kind, img in (("raw", raw), ("final", final)):
+            crop_stats(f"{tag}_{kind}", img, out, crop=min(128, pn))
+            if pn <= 200:
+                out[f"{tag}_{kind}_image"] = img.contiguous()
+        print(f"   {tag}: N {N}  K {K}  final {tuple(final.shape)}  sum {float(final.double().sum()):.7e}", flush=True)
+    # a consecutive run at 1000^2
+    pn, lo, n = 1000, 30000, 600
+    mk = quiet(ref_mask.Mask, odd_mask(pn), PS, CPU)
+    mft = mk.fraunhofer(WL, True)
+    full = source("annular", pn, 0.4, 0.8)
+    pts = torch.argwhere(full)
+    bm = torch.zeros_like(full)
+    sel = pts[lo:lo + n]
+    bm[sel[:, 0], sel[:, 1]] = 1
+    final, raw = full_image_with_raw(mk, mft, pupil_fn(pn, DEMO_AB), bm)
+    out["run1000_range"] = np.array([lo, lo + n, pts.shape[0]], dtype=np.int64)
+    out["run1000_first_last_shift"] = shifts_of(bm, pn)[[0, -1]]
+    for kind, img in (("raw", raw), ("final", final)):
+        crop_stats(f"run1000_{kind}", img, out)
+        out[f"run1000_{kind}_stride8"] = img[::8, ::8].contiguous()
+    print(f"   run1000: points [{lo},{lo + n}) of {pts.shape[0]}  final sum {float(final.double().sum()):.7e}", flush=True)
+    save("g16_odd_sizes.npz", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     if os.environ.get("LITHO_GOLDEN_THREADS"):
@@ -569,4 +616,4 @@ if __name__ == "__main__":
     for g in which:
         {"g1": g1_sources, "g2": g2_pupils, "g3": g3_mask_spectra, "g4": g4_fields,
          "g5": g5_images, "g6": g6_through_focus, "g8": g8_large_pupils, "g9": g9_config5_stack, "g10": g10_contiguous_shards,
-         "g11": g11_config2_full, "g12": g12_shard4096, "g13": g13_config3_long_run, "g14": g14_config3_rank_shard, "g15": g15_config5_stack_run}[g]()
+         "g11": g11_config2_full, "g12": g12_shard4096, "g13": g13_config3_long_run, "g14": g14_config3_rank_shard, "g15": g15_config5_stack_run, "g16": g16_odd_sizes}[g]()

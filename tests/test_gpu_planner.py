@@ -310,6 +310,52 @@ def test_odd_mask_sizes_run_embedded_and_match_the_oracle(L, dev, monkeypatch, p
     assert rel_max((norm * K).cpu(), img1.cpu()) < 1e-6
 
 
+@pytest.mark.parametrize("embed", [1, 0])
+def test_odd_mask_sizes_vs_the_reference_itself(golden, L, dev, embed):
+    """Golden g16: 200^2, 1000^2, 1500^2 masks through the REFERENCE's own abbeImage (its torch.fft path takes any size and
+    knows nothing of padded grids) -- strided points at each size and 600 consecutive points at 1000^2 (long enough for the
+    coarse grid of the padded 1024^2).  The engine's embedded evaluation (and, embed = 0, its generic kernels) against raw and
+    final images: full image at 200^2 (final 198 x 198, the reference's pad arithmetic), crops and every row / column sum above."""
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    g = golden("g16_odd_sizes.npz")
+    for tag, pn in (("p200", 200), ("p1000", 1000), ("p1500", 1500), ("run1000", 1000)):
+        mask = L.Mask(bernoulli_mask(pn), PS, dev)
+        mft = mask.fraunhofer(WL, True)
+        eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+        pf = L.Pupil(pn, WL, NA, f16([0, 0, 0.01, 0, 100, 0.01, 0, 0.01, 0.01, 0.01]), dev).generatePupilFunction()
+        sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateAnnular(), pn)
+        if tag == "run1000":
+            lo, hi, S = (int(v) for v in g["run1000_range"])
+            assert sh.shape[0] == S
+            sel = sh[lo:hi]
+            assert np.array_equal(sel[[0, -1]].cpu().numpy(), g["run1000_first_last_shift"])
+        else:
+            assert N == int(g[f"{tag}_N"]) and sh.shape[0] == int(g[f"{tag}_S_full"])
+            sel = torch.from_numpy(g[f"{tag}_shifts"]).to(dev)
+        raw = L.abbeIntensity(mft, pf, sel, N, options={"embed": embed})
+        plan = nat().last_plan()
+        assert plan["general"] == 0 and (plan["variant"] >= 0) == bool(embed), (tag, plan)
+        if tag == "run1000":
+            assert plan["coarse_grid"] == embed, plan                         # 600 points >= 256 at the padded 1024^2
+        final = L.postProcess(raw, eps).cpu()
+        raw = raw.cpu()
+        assert tuple(final.shape) == tuple(g[f"{tag}_final_shape"])
+        for kind, img in (("raw", raw), ("final", final)):
+            mx = float(g[f"{tag}_{kind}_max"])
+            crop = min(128, img.shape[0])
+            c0 = img.shape[0] // 2 - crop // 2
+            e = float((img[c0:c0 + crop, c0:c0 + crop].double() - torch.from_numpy(g[f"{tag}_{kind}_crop"]).double()).abs().max() / mx)
+            if f"{tag}_{kind}_image" in g.files:
+                e = max(e, float((img.double() - torch.from_numpy(g[f"{tag}_{kind}_image"]).double()).abs().max() / mx))
+            if f"{tag}_{kind}_stride8" in g.files:
+                e = max(e, float(np.abs(img[::8, ::8].numpy().astype(np.float64) - g[f"{tag}_{kind}_stride8"]).max() / mx))
+            print(f"{tag} ({pn}^2, embed {embed}) vs the reference, {kind}: {e:.2e} of the maximum")
+            assert e < TOL_IMAGE_MAX, (tag, kind, e)
+            assert np.allclose(img.double().sum(1).numpy(), g[f"{tag}_{kind}_rowsum"], rtol=2e-5, atol=2e-6 * float(np.abs(g[f"{tag}_{kind}_rowsum"]).max()))
+            assert np.allclose(img.double().sum(0).numpy(), g[f"{tag}_{kind}_colsum"], rtol=2e-5, atol=2e-6 * float(np.abs(g[f"{tag}_{kind}_colsum"]).max()))
+            assert abs(float(img.double().sum()) / float(g[f"{tag}_{kind}_sum"]) - 1) < 2e-6
+
+
 @pytest.mark.parametrize("pn", [200, 1000])
 def test_embedded_evaluation_refuses_shifts_that_wrap_the_original_grid(L, dev, pn):
     """The reference rolls the pupil modulo ITS grid (imageformation.py:63).  In the padded grid a large shift has room

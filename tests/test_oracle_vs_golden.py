@@ -183,6 +183,25 @@ def test_other_fft_sizes(golden, ps):
     assert rel_max(final, g[f"bern64_ps{ps}_final"]) < TOL_IMAGE_MAX
 
 
+def test_odd_mask_size_200(golden):
+    """A mask size that is not a power of two, by the reference (golden g16): 200^2, N = 512, 24 strided points of the annular
+    source, the whole raw and final image -- the final one is 198 x 198 (the reference's pad arithmetic, as 4096 -> 4094)."""
+    g = golden("g16_odd_sizes.npz")
+    pn = 200
+    mft = O.mask_spectrum(bernoulli_mask(pn), PS, WL)
+    eps, N = O.calculate_epsilon_n(4 / pn, PS, WL)
+    assert N == int(g["p200_N"]) == 512
+    bm = O.source_annular(0.4, 0.8, pn)
+    assert int(bm.sum()) == int(g["p200_S_full"])
+    sh = torch.from_numpy(g["p200_shifts"])
+    pf = O.pupil_function(f16(DEMO_AB), pn, NA, WL)
+    raw = O.abbe_raw(mft, pf, sh, N)
+    assert rel_max(raw, g["p200_raw_image"]) < TOL_IMAGE_MAX and rel_l2(raw, g["p200_raw_image"]) < TOL_IMAGE_L2
+    final = O.post_process(raw, eps)
+    assert tuple(final.shape) == (198, 198) == tuple(g["p200_final_shape"])
+    assert rel_max(final, g["p200_final_image"]) < TOL_IMAGE_MAX
+
+
 def test_n_smaller_than_mask_raises():
     mft = O.mask_spectrum(bernoulli_mask(64), 25, WL)
     with pytest.raises(RuntimeError):

@@ -154,6 +154,9 @@ typedef struct litho_abbe_options {
     int32_t poison;          /* 1: scratch starts the call as NaN bit patterns (tests) */
     int32_t embed;           /* 0: run mask sizes other than N and N / 2 on the generic kernels at their own size instead of
                               * embedded in the next such grid (litho_abbe_embedded_size; default 1) */
+    int32_t split;           /* 0: a source list in which SOME shifts wrap the pupil around the grid (shifted, off-axis sources) runs
+                              * the general path for every point instead of being split into a non-wrapping part (every fast
+                              * path) and a wrapping one (general path) on the device (default 1: from 256 source points; 2: always) */
 } litho_abbe_options;
 int litho_abbe_accumulate_opts(const void *maskFT, const void *pupil, int planes, const int32_t *shifts,
                                const int32_t *count_dev, int64_t capacity, int pn, int N, float *out,
@@ -205,7 +208,8 @@ int litho_mask_spectrum(const int16_t *geometry, int pn, double epsilon, int N, 
  * [12]=1 when the coarse-grid path ran (pn-point transforms on the grid q = 2 v, fine image reconstructed once
  * per plane), [13]=1 when the y-pass ran a wave-level kernel (k_ypass_rect / k_ypass_wave / k_ypass_pair), [14]=1 when
  * the pupil's support box lies inside the natural support |k| <= pn/4, [15]=1 when the call planned from a caller-held
- * record (litho_abbe_accumulate_planned). */
+ * record (litho_abbe_accumulate_planned), 2 when the source list was split into a non-wrapping and a wrapping part (the other
+ * fields then describe the part that ran last, the wrapping one if there is one; [6] counts both). */
 int litho_abbe_last_plan(int64_t fields_host[16]);
 
 /* Names of the x-pass and y-pass kernels the last litho_abbe_accumulate on this thread launched in its source-point

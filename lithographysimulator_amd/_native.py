@@ -169,7 +169,7 @@ class PlanRecord(ctypes.Structure):
 class Options(ctypes.Structure):
     """litho_abbe_options (include/litho_abbe.h): per-call launch-planner options; -1 = not set."""
     _names = ("coarse", "batch", "groups", "xchunk", "tile", "plane_chunk", "w64", "rect", "w64_8192", "xsplit", "xrect",
-              "w64x", "gcombine", "rowpairs", "force_generic", "force_general", "poison", "embed")
+              "w64x", "gcombine", "rowpairs", "force_generic", "force_general", "poison", "embed", "split")
     _fields_ = [("size", ctypes.c_int32)] + [(n, ctypes.c_int32) for n in _names]
 
     @classmethod

@@ -287,6 +287,92 @@ __global__ void k_nyquist_apply(float* __restrict__ img, const float2* __restric
 }
 
 // ----------------------------------------------------------------------------------
+// Splitting a source list whose shifts wrap the pupil around the grid for SOME of its points (shifted, off-axis sources:
+// LightSource(shiftX, shiftY), lightsource.py:5): the points that do not wrap keep every fast path (pruned box, wave kernels,
+// coarse grid, embedding), only the wrapping ones need the general one (roll kept on P, modular gather, full window: 4x the
+// time per point).  Stable, deterministic two-list compaction in three small kernels; 1024 points per block, 4 consecutive
+// points per thread.
+// ----------------------------------------------------------------------------------
+struct SplitBox { int r0, r1, c0, c1, pn; };
+__device__ __forceinline__ bool shift_wraps(int dy, int dx, const SplitBox& b)
+{
+    return b.r0 + dy < 0 || b.r1 + dy > b.pn - 1 || b.c0 + dx < 0 || b.c1 + dx > b.pn - 1;
+}
+static constexpr int SPLIT_PER_BLOCK = 1024;
+__global__ __launch_bounds__(256) void k_split_count(const int* __restrict__ shifts, long long S, SplitBox b, int* __restrict__ counts)
+{
+    __shared__ int red[4];
+    const long long base = (long long)blockIdx.x * SPLIT_PER_BLOCK + 4 * threadIdx.x;
+    int n = 0;
+    for (int i = 0; i < 4; ++i)
+        if (base + i < S && !shift_wraps(shifts[2 * (base + i)], shifts[2 * (base + i) + 1], b)) ++n;
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// exclusive scan of the block counts (one block walks them; at most pn^2 / 1024 entries) + the two totals and empty extents
+__global__ __launch_bounds__(1024) void k_split_scan(int* __restrict__ counts, int nblocks, long long S, int* __restrict__ words)
+{
+    __shared__ int part[1024];
+    const int per = (nblocks + 1023) / 1024, lo = threadIdx.x * per, hi = min(nblocks, lo + per);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += counts[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < 1024; ++i) { const int v = part[i]; part[i] = run; run += v; }
+        words[0] = run; words[1] = (int)(S - run);
+        for (int i = 0; i < 2; ++i) { words[2 + 4 * i] = INT_MAX; words[3 + 4 * i] = INT_MIN; words[4 + 4 * i] = INT_MAX; words[5 + 4 * i] = INT_MIN; }
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int i = lo; i < hi; ++i) { const int v = counts[i]; counts[i] = run; run += v; }
+}
+__global__ __launch_bounds__(256) void k_split_write(const int* __restrict__ shifts, long long S, SplitBox b, const int* __restrict__ offsets,
+                                                     int* __restrict__ list_a, int* __restrict__ list_b, int* __restrict__ words)
+{
+    __shared__ int scan[256];
+    const long long block0 = (long long)blockIdx.x * SPLIT_PER_BLOCK, base = block0 + 4 * threadIdx.x;
+    int dy[4], dx[4];
+    bool ok[4], wr[4];
+    int n = 0;
+    for (int i = 0; i < 4; ++i) {
+        ok[i] = base + i < S;
+        dy[i] = ok[i] ? shifts[2 * (base + i)] : 0;
+        dx[i] = ok[i] ? shifts[2 * (base + i) + 1] : 0;
+        wr[i] = ok[i] && shift_wraps(dy[i], dx[i], b);
+        if (ok[i] && !wr[i]) ++n;
+    }
+    scan[threadIdx.x] = n;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {                   // inclusive Hillis-Steele scan of the per-thread counts
+        const int v = threadIdx.x >= off ? scan[threadIdx.x - off] : 0;
+        __syncthreads();
+        scan[threadIdx.x] += v;
+        __syncthreads();
+    }
+    long long ia = (long long)offsets[blockIdx.x] + scan[threadIdx.x] - n;          // rank among the non-wrapping points
+    long long ib = base - ia;                                                       // ... and among the wrapping ones (this thread's first point)
+    int e[8] = {INT_MAX, INT_MIN, INT_MAX, INT_MIN, INT_MAX, INT_MIN, INT_MAX, INT_MIN};
+    for (int i = 0; i < 4; ++i) {
+        if (!ok[i]) continue;
+        int* dst = wr[i] ? list_b + 2 * ib++ : list_a + 2 * ia++;
+        dst[0] = dy[i]; dst[1] = dx[i];
+        int* x = e + (wr[i] ? 4 : 0);
+        x[0] = min(x[0], dy[i]); x[1] = max(x[1], dy[i]); x[2] = min(x[2], dx[i]); x[3] = max(x[3], dx[i]);
+    }
+    for (int k = 0; k < 8; ++k)
+        for (int off = 32; off > 0; off >>= 1) e[k] = (k & 1) ? max(e[k], __shfl_xor(e[k], off)) : min(e[k], __shfl_xor(e[k], off));
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 8; ++k) {
+            if (k & 1) { if (e[k] != INT_MIN) atomicMax(&words[2 + k], e[k]); }
+            else if (e[k] != INT_MAX) atomicMin(&words[2 + k], e[k]);
+        }
+}
+
+// ----------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------
 struct Workspace {
@@ -423,7 +509,7 @@ static int env_int(const char* name, int dflt)
 // Tuning / test knobs.  Resolved ONCE per C-ABI call, never per launch: a field of the caller's litho_abbe_options that is
 // >= 0 wins, otherwise the LITHO_ABBE_* environment variable, otherwise the default.
 struct Knobs {
-    int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk, xsplit, rect, xrect, coarse, gcombine, rowpairs, poison, embed;
+    int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk, xsplit, rect, xrect, coarse, gcombine, rowpairs, poison, embed, split;
     static int pick(const litho_abbe_options* o, size_t off, const char* name, int dflt)
     {
         if (o && off + sizeof(int32_t) <= (size_t)o->size) {
@@ -454,6 +540,7 @@ struct Knobs {
         LITHO_KNOB(rowpairs, "LITHO_ABBE_ROWPAIRS", 0);
         LITHO_KNOB(poison, "LITHO_ABBE_POISON", 0);
         LITHO_KNOB(embed, "LITHO_ABBE_EMBED", 1);
+        LITHO_KNOB(split, "LITHO_ABBE_SPLIT", 1);
 #undef LITHO_KNOB
         return k;
     }
@@ -944,6 +1031,10 @@ static int accumulate_planned(const float2* M, const float2* P, int planes, cons
     return LITHO_OK;
 }
 
+static constexpr int64_t SPLIT_MIN_POINTS = 256;          // below that the two extra launches and the read-back cost more than they save
+static int accumulate_embedded(const float2* M, const float2* P, int planes, const int* shifts, int64_t S, const int pl[PLAN_WORDS],
+                               int pn, int pe, int N, float* out, void* ws, size_t ws_bytes, size_t t_cap, const Knobs& kn,
+                               const SizeOps* ops, hipStream_t st);
 void launch_embed_c64(const float2* src, int planes, int pn, float2* dst, int pe, hipStream_t st);     // optics.hip
 void launch_crop_add_f32(const float* src, int planes, int pe, float* dst, int pn, hipStream_t st);
 
@@ -1008,10 +1099,74 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     // Embedded evaluation -- unless a shift wraps the pupil around the CALLER's grid: the reference rolls modulo its own size
     // (imageformation.py:63), which the padded grid would not reproduce; such a list runs the general path at this size.
     const bool nowrap = pl[0] + pl[4] >= 0 && pl[1] + pl[5] <= pn - 1 && pl[2] + pl[6] >= 0 && pl[3] + pl[7] <= pn - 1;
+    if (!nowrap && !kn.force_general && kn.split && !from_record && (S >= SPLIT_MIN_POINTS || kn.split >= 2)) {
+        // Some shift wraps the pupil around the grid -- usually for a minority of the points of a shifted source.  Split the
+        // list (stable, on the device; one more 40-byte read-back) and give each part the path it needs: this function
+        // again for the non-wrapping points (pruned box, coarse grid, embedding: 2.5 us per point at 1024^2), the
+        // general path for the others (10 us).  The two lists live at the end of the T region, which shrinks by them.
+        // (absolute placement: the lists end where the T region of the grid the non-wrapping part runs at ends -- the
+        // padded grid's for an embedded size -- and BOTH carves' T regions are cut short of them)
+        const size_t list_bytes = align_up((size_t)S * 2 * sizeof(int), 256);
+        const size_t t_end = pe != pn ? workspace_bytes_at(pe, N) : workspace_bytes_at(pn, N);
+        const size_t list_start = t_end - 2 * list_bytes;
+        const size_t t0_own = (size_t)((unsigned char*)w.T - (unsigned char*)ws);
+        const size_t t0_pad = pe != pn ? workspace_bytes_at(pe, N) - t_budget(pe) : t0_own;
+        const size_t room = (size_t)64 << 20;
+        if (2 * list_bytes < t_end && list_start > t0_own + room && list_start > t0_pad + room) {
+            Workspace ws_split = w;
+            if (t0_own + ws_split.t_bytes > list_start) ws_split.t_bytes = list_start - t0_own;
+            int* list_a = (int*)((unsigned char*)ws + list_start);
+            int* list_b = (int*)((unsigned char*)list_a + list_bytes);
+            int* counts = (int*)w.T;                                      // block counts: the head of T, free until the loops start
+            int* words = w.plan + 32;
+            const SplitBox box{pl[0], pl[1], pl[2], pl[3], pn};
+            const int nblocks = (int)((S + SPLIT_PER_BLOCK - 1) / SPLIT_PER_BLOCK);
+            hipLaunchKernelGGL(k_split_count, dim3(nblocks), dim3(256), 0, st, shifts, (long long)S, box, counts);
+            hipLaunchKernelGGL(k_split_scan, dim3(1), dim3(1024), 0, st, counts, nblocks, (long long)S, words);
+            hipLaunchKernelGGL(k_split_write, dim3(nblocks), dim3(256), 0, st, shifts, (long long)S, box, counts, list_a, list_b, words);
+            HIP_TRY(hipGetLastError());
+            int sw[10];
+            HIP_TRY(hipMemcpyAsync(sw, words, sizeof(sw), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            int64_t launches = 0;
+            for (int part = 0; part < 2; ++part) {
+                const int64_t n = sw[part];
+                if (n <= 0) continue;
+                int plp[PLAN_WORDS];
+                for (int i = 0; i < PLAN_WORDS; ++i) plp[i] = pl[i];
+                for (int i = 0; i < 4; ++i) plp[4 + i] = sw[2 + 4 * part + i];
+                plp[8] = (int)n;
+                const int* lst = part == 0 ? list_a : list_b;
+                // part 0 cannot wrap (it may run embedded); part 1 wraps by construction: general mode at this size
+                if (part == 0 && pe != pn) rc = accumulate_embedded(M, P, planes, lst, n, plp, pn, pe, N, out, ws, ws_bytes, list_start, kn, ops, st);
+                else rc = accumulate_planned(M, P, planes, lst, n, plp, pn, N, out, ws_split, kn, ops, st);
+                if (rc) return rc;
+                launches += g_last_plan[6];
+            }
+            g_last_plan[6] = launches;                                    // (the other fields describe the part that ran last)
+            g_last_plan[15] = 2;                                          // = the source list was split
+            return LITHO_OK;
+        }
+    }
     if (pe == pn || !nowrap || kn.force_general) return accumulate_planned(M, P, planes, shifts, S, pl, pn, N, out, w, kn, ops, st);
+    return accumulate_embedded(M, P, planes, shifts, S, pl, pn, pe, N, out, ws, ws_bytes, 0, kn, ops, st);
+}
+
+// The embedded evaluation of a non-wrapping source list: pad into the scratch behind the padded size's workspace regions, run at
+// pe, add the centre back.  t_cap > 0: byte offset in the workspace at which the T region must end (the lists of a split
+// source list follow it).
+static int accumulate_embedded(const float2* M, const float2* P, int planes, const int* shifts, int64_t S, const int pl[PLAN_WORDS],
+                               int pn, int pe, int N, float* out, void* ws, size_t ws_bytes, size_t t_cap, const Knobs& kn,
+                               const SizeOps* ops, hipStream_t st)
+{
+    int rc;
 
     Workspace w2;
-    if (!carve(ws, ws_bytes, pe, N, w2)) return LITHO_E_WORKSPACE;          // (cannot fail: checked above)
+    if (!carve(ws, ws_bytes, pe, N, w2)) return LITHO_E_WORKSPACE;          // (cannot fail: checked by the caller)
+    if (t_cap > 0) {
+        const size_t t0 = (size_t)((unsigned char*)w2.T - (unsigned char*)ws);
+        if (t0 + w2.t_bytes > t_cap) w2.t_bytes = t_cap - t0;
+    }
     unsigned char* extra = (unsigned char*)ws + workspace_bytes_at(pe, N);
     const size_t e2 = (size_t)pe * pe;
     float2* M2 = (float2*)extra;

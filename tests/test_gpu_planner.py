@@ -380,6 +380,57 @@ def test_embedded_evaluation_refuses_shifts_that_wrap_the_original_grid(L, dev, 
         _check(got, want, f"{pn}^2 shift {edge - past} (wraps the original grid: {past})")
 
 
+# ------------------------------------------------------------------ shifted (off-axis) sources: the list is split
+@pytest.mark.parametrize("pn,K", [(512, 420), (1000, 300), (256, 40)])
+def test_shifted_source_is_split_into_a_fast_and_a_general_part(L, dev, pn, K):
+    """LightSource(shiftX, shiftY) (lightsource.py:5) moves the whole source: for part of its points the rolled pupil wraps
+    around the grid, which only the general path reproduces (4x the time per point).  The list is split on the device -- stable,
+    deterministic -- so that only the wrapping points pay: against the oracle (whose torch.roll wraps), against the unsplit
+    general evaluation, at a power-of-two size, at an embedded one (the non-wrapping part runs padded, the other at the caller's
+    size) and below the automatic threshold with split = 2; all-wrapping and none-wrapping lists as the degenerate cases."""
+    o = O()
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    pupil = L.Pupil(pn, WL, NA, f16([0, 0, 0.01, 0, 70]), dev).generatePupilFunction()
+    sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, shiftX=0.25, shiftY=-0.5, device=dev).generateAnnular(), pn)
+    sel = sh[(torch.arange(K, device=dev) * sh.shape[0]) // K].contiguous()
+    c, h = pn // 2, pn // 4
+    wraps = (sel[:, 0] < -(c - h)) | (sel[:, 0] > (pn - 1) - (c + h)) | (sel[:, 1] < -(c - h)) | (sel[:, 1] > (pn - 1) - (c + h))
+    nw = int(wraps.sum())
+    assert 0 < nw < K, (nw, K)
+    ref = _oracle_chunked(o, mft.cpu(), pupil.cpu(), sel.cpu(), N)
+    mode = 2 if K < 256 else 1
+    got = L.abbeIntensity(mft, pupil, sel, N, options={"split": mode}).cpu()
+    plan = nat().last_plan()
+    assert plan["planned_from_record"] == 2 and plan["general"] == 1, plan                  # split; the wrapping part ran last
+    _check(got, ref, f"{pn}^2 shifted source, {nw} of {K} points wrap, split")
+    whole = L.abbeIntensity(mft, pupil, sel, N, options={"split": 0}).cpu()
+    plan0 = nat().last_plan()
+    assert plan0["planned_from_record"] == 0 and plan0["general"] == 1 and plan0["launches"] < plan["launches"] + 1, (plan0, plan)
+    _check(whole, ref, f"{pn}^2 shifted source, unsplit general evaluation")
+    # a stack, into a pre-filled buffer
+    stack = L.throughFocusPupils(pn, WL, NA, f16([0, 0, 0.01, 0, 70]), [-50.0, 30.0], dev)
+    pre = torch.full((2, pn, pn), 0.1 * float(ref.max()), device=dev)
+    both = L.abbeIntensity(mft, stack, sel, N, out=pre.clone(), options={"split": mode}).cpu()
+    assert nat().last_plan()["planned_from_record"] == 2
+    for k in range(2):
+        _check(both[k], pre[k].cpu().double() + _oracle_chunked(o, mft.cpu(), stack[k].cpu(), sel.cpu(), N), f"{pn}^2 shifted source, stack plane {k}")
+    # degenerate lists: every point wraps / none does (no split happens for the second: nothing wraps)
+    only_w, only_n = sel[wraps].contiguous(), sel[~wraps].contiguous()
+    a = L.abbeIntensity(mft, pupil, only_w, N, options={"split": 2}).cpu()
+    assert nat().last_plan()["planned_from_record"] == 2 and nat().last_plan()["general"] == 1
+    b = L.abbeIntensity(mft, pupil, only_n, N, options={"split": 2}).cpu()
+    assert nat().last_plan()["planned_from_record"] == 0 and nat().last_plan()["general"] == 0
+    _check(a.double() + b.double(), ref, f"{pn}^2 shifted source, wrapping and non-wrapping halves separately")
+    # end to end through abbeImage with the shifted bitmap
+    few = torch.zeros((pn, pn), dtype=torch.int64, device=dev)
+    few[(sel[:, 0] + c).long(), (sel[:, 1] + c).long()] = 1
+    img = L.abbeImage(mask, mft, pupil, few, PS, mask.deltaK, WL, True, dev, options={"split": mode}).cpu()
+    _check(img, o.post_process(ref.float(), eps), f"{pn}^2 shifted source through abbeImage")
+
+
 def test_environment_variables_remain_a_fallback_and_options_win(L, dev, monkeypatch):
     """Options passed per call beat the LITHO_ABBE_* variables; a field the caller leaves unset falls back to the variable,
     then to the default."""
@@ -470,7 +521,7 @@ def _fuzz_case(seed):
     for name, values in (("batch", [0, 0, 1, 2, 3, 5, 8]), ("groups", [0, 0, 1, 2, 3, 4]), ("xchunk", [0, 0, 1, 2, 3]),
                          ("tile", [0, 0, 4, 8]), ("plane_chunk", [0, 1, 2, 4]), ("gcombine", [1, 1, 0]),
                          ("rect", [1, 1, 0]), ("w64", [1, 1, 1, 0]), ("xrect", [1, 1, 0, 2]), ("force_generic", [0, 0, 0, 1]),
-                         ("force_general", [0, 0, 0, 0, 1])):
+                         ("force_general", [0, 0, 0, 0, 1]), ("split", [1, 2, 2, 0]), ("embed", [1, 1, 0])):
         opts[name] = pick(values)
     pupils = torch.stack([_fuzz_pupil(gen, kind, pn) for _ in range(planes)])
     mft = torch.complex(torch.randn(pn, pn, generator=gen), torch.randn(pn, pn, generator=gen))

@@ -779,7 +779,9 @@ def test_plan_cache_notices_another_pupil_or_source(L, dev):
     """Round-3 advice: a PlanCache reused with a DIFFERENT pupil tensor (a wider support box: the recorded box would
     prune live rows), an in-place edit of the same tensor, or another source bitmap used to give a silently wrong image.
     The cache now remembers which tensors it was made for (address, shape, version counter -- host-side only) and plans
-    afresh; unchanged tensors keep the no-wait path; plan_cache with group= is refused."""
+    afresh; unchanged tensors keep the no-wait path; plan_cache with group= is refused.  (planned_from_record: 0 = planned
+    afresh, 1 = from the record, 2 = planned afresh and the source list split -- the wide pupil wraps for part of the second
+    source's points.)"""
     from lithographysimulator_amd import _native as nat
     from lithographysimulator_amd.synthetic import bernoulli_mask
     pn = 256
@@ -792,27 +794,27 @@ def test_plan_cache_notices_another_pupil_or_source(L, dev):
     wide[pn // 2 - 3:pn // 2 + 3, pn // 2 + pn // 4 + 1:pn // 2 + pn // 4 + 30] = 0.5 + 0.5j     # beyond the recorded box
     img = lambda p, b, **kw: L.abbeImage(mk, mft, p, b, PS, mk.deltaK, WL, True, dev, **kw)      # noqa: E731
     cache = L.PlanCache()
-    assert torch.equal(img(pf, bm, plan_cache=cache), img(pf, bm)) and nat.last_plan()["planned_from_record"] == 0
+    assert torch.equal(img(pf, bm, plan_cache=cache), img(pf, bm)) and nat.last_plan()["planned_from_record"] != 1
     assert torch.equal(img(pf, bm, plan_cache=cache), img(pf, bm))
     img(pf, bm, plan_cache=cache)
     assert nat.last_plan()["planned_from_record"] == 1                                          # unchanged: no-wait path
     got = img(wide, bm, plan_cache=cache)                                                        # another pupil tensor
-    assert nat.last_plan()["planned_from_record"] == 0 and torch.equal(got, img(wide, bm))
+    assert nat.last_plan()["planned_from_record"] != 1 and torch.equal(got, img(wide, bm))
     assert not torch.equal(got, img(pf, bm))
     got = img(wide, bm2, plan_cache=cache)                                                       # another source bitmap
-    assert nat.last_plan()["planned_from_record"] == 0 and cache.S == int(bm2.sum()) and torch.equal(got, img(wide, bm2))
+    assert nat.last_plan()["planned_from_record"] != 1 and cache.S == int(bm2.sum()) and torch.equal(got, img(wide, bm2))
     img(wide, bm2, plan_cache=cache)
     assert nat.last_plan()["planned_from_record"] == 1
     wide[pn // 2 + pn // 4 + 5, pn // 2] = 1.0                                                   # in-place edit, same tensor
     got = img(wide, bm2, plan_cache=cache)
-    assert nat.last_plan()["planned_from_record"] == 0 and torch.equal(got, img(wide, bm2))
+    assert nat.last_plan()["planned_from_record"] != 1 and torch.equal(got, img(wide, bm2))
     # the explicit-list form
     eps, N = mk.calculateEpsilonN(mk.deltaK, PS, WL)
     sh, sh2 = L.sourceShifts(bm, pn), L.sourceShifts(bm2, pn)
     c2 = L.PlanCache()
     L.abbeIntensity(mft, pf, sh, N, plan=c2)
     a, S = L.abbeIntensity(mft, wide, sh2, N, plan=c2)
-    assert nat.last_plan()["planned_from_record"] == 0 and S == sh2.shape[0] and torch.equal(a, L.abbeIntensity(mft, wide, sh2, N))
+    assert nat.last_plan()["planned_from_record"] != 1 and S == sh2.shape[0] and torch.equal(a, L.abbeIntensity(mft, wide, sh2, N))
     with pytest.raises(ValueError):
         L.abbeImage(mk, mft, pf, bm, PS, mk.deltaK, WL, True, dev, plan_cache=cache, group=object())
 

@@ -97,7 +97,9 @@ int litho_abbe_embedded_size(int pn, int N, int *size_host);
  * stack sharing maskFT and the source list); shifts int32 [S,2] = (dy,dx) =
  * (row - pn/2, col - pn/2); out fp32 [planes,pn,pn], accumulated into (the caller zeroes
  * it, and all-reduces it across GPUs when the source list is sharded).
- * Reads back 56 bytes once (pupil support box, its edge supports, shift extents, count) to plan the launch.
+ * Reads back 56 bytes once (pupil support box, its edge supports, shift extents, count) to plan the launch -- and 40 more,
+ * once, when some but not all shifts of the list wrap the pupil around the grid (a shifted source: the list is then split on
+ * the device into a part that keeps the fast paths and a part that needs the general one; options.split).
  * How the sum is evaluated is the library's business: for N = 2 pn, pn = 256 .. 4096 and a source list long
  * enough to repay it, the loop runs pn-point transforms on the grid q = 2 v and the fine image is reconstructed
  * once per call and plane; same result to rounding.  Environment, read once per call:

@@ -175,16 +175,27 @@ struct WaveSq {
         dft_dif(x);                                    // slot brev(m) = y[m]
         run_tail(x, tw, lds, lane);
     }
-    // everything after pass A
-    __device__ static __forceinline__ void run_tail(float2 (&x)[S], const LaneTwiddles& tw, float* lds, int lane)
+    // the lane twiddles w_{S*S}^(l m) on the outputs of pass A (slot brev(m) = y[m])
+    __device__ static __forceinline__ void lane_twiddle_mul(float2 (&x)[S], const LaneTwiddles& tw)
     {
-        const int l = lane & (S - 1), line = lane >> LS;
         static_for<0, S>([&](auto m_) {
             constexpr int m = decltype(m_)::value;
             constexpr int a = m >> 3, b = m & 7, sl = brev(m);
             if constexpr (b != 0) x[sl] = cmul(x[sl], tw.row[b]);
             if constexpr (a != 0) x[sl] = cmul(x[sl], tw.row[8 + a]);
         });
+    }
+    // everything after pass A
+    __device__ static __forceinline__ void run_tail(float2 (&x)[S], const LaneTwiddles& tw, float* lds, int lane)
+    {
+        lane_twiddle_mul(x, tw);
+        transpose(x, lds, lane);
+        dft_dif(x);                                    // slot brev(k2) = X[l + S k2]
+    }
+    // slot brev(m) of lane l  ->  slot l of lane m (natural slot order on return)
+    __device__ static __forceinline__ void transpose(float2 (&x)[S], float* lds, int lane)
+    {
+        const int l = lane & (S - 1), line = lane >> LS;
         // S x S transpose, real parts then imaginary parts, through this line's private matrix:
         // element (row = writer lane, col = m); reader lane m takes column m.
         float* const mat = lds + line * (S * (S + 1));
@@ -206,7 +217,6 @@ struct WaveSq {
         });
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        dft_dif(x);                                    // slot brev(k2) = X[l + S k2]
     }
 
     // ------------------------------------------------------------------------------------------------

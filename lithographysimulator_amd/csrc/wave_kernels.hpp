@@ -337,6 +337,173 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ypass_coop(
 }
 
 // ----------------------------------------------------------------------------------
+// k_ypass_coop with the NEXT line's samples in flight while the current line is transformed (round 5).  k_ypass_coop is
+// latency-bound: per line a wave issues its 17 loads, waits, deals, waits at a barrier, and only then has arithmetic to do, and
+// at two waves per SIMD (64 samples + 64 accumulators per lane) the partner of a waiting wave issues at the lone-wave rate
+// (profiles/r04_pmc_cfg4_summary.txt: VALU busy 33 %, 0.35 of the HBM peak).  There are no registers for a prefetch (68 more)
+// and no LDS for a second staging area -- but the staging area IS the transpose matrix, and that is idle from the end of a
+// line's transposes to the start of the next line's: 60 % of the line (pass B + accumulation).  So the loads of line s + G are
+// issued right after the transposes of line s as LDS-DMA (buffer_load_dwordx4 ... lds: no register, no deal), each wave INTO
+// ITS OWN region (its matrix: free as soon as its own transposes are done -- no barrier needed before the issue), and every
+// wave reads its column out of all four regions after the barrier at the top of the next line.  One DMA instruction = 32 rows
+// x 32 bytes = 1 KB of LDS in lane order; the lane -> (row, 16-byte half) assignment is swizzled (half ^= bit 3 of the row) so
+// that the 64 8-byte reads of a column spread over all banks.  Two workgroup barriers per line, as before:
+//   B1 (top): every wave's DMA has landed (each waits vmcnt(0) first)            -> read x from the regions
+//   B2 (after pass A + lane twiddles): every wave has read its x                 -> the matrices may overwrite the regions
+// ----------------------------------------------------------------------------------
+template <int NW>
+struct CoopDmaShape {
+    static_assert(NW == 4, "four waves share four columns (32 bytes) of a tile row");
+    static constexpr int S = 64, N = 4096, JLIVE = 16, NLIVE = 2 * JLIVE + 1;
+    static constexpr int UNITS = (NLIVE + 1) / 2;                                   // 1 KB units (32 rows x 32 bytes) per wave and line
+    static constexpr int WAVE_BYTES = UNITS * 1024;                                 // 17 KB >= the 64 x 65 fp32 matrix
+    static_assert(WAVE_BYTES >= WaveSq<6>::LDS_FLOATS * 4 && WAVE_BYTES % 256 == 0, "a region holds the transpose matrix; regions bank-aligned");
+    static constexpr size_t LDS_BYTES = NW * (size_t)WAVE_BYTES + (size_t)WaveSq<6>::TW_LDS_FLOAT2 * sizeof(float2);
+    static constexpr int PARTS = 16 / NW;
+    static inline int grid_x(int pn) { return PARTS * (((pn + 15) / 16 + 7) / 8 * 8); }
+};
+
+// one LDS-DMA instruction: lane i's 16 bytes at byte offset `voff` of the buffer -> LDS bytes [16 i, 16 i + 16) of `dst`
+// (dst is wave-uniform: it travels in M0); out-of-range lanes deliver zeros
+#ifndef LITHO_COOP_DMA_AUX                // cache-policy bits (build-time experiment hook: sc0 = 1, nt = 2, sc1 = 16)
+#define LITHO_COOP_DMA_AUX 0
+#endif
+__device__ __forceinline__ void dma_b128_to_lds(__amdgpu_buffer_rsrc_t r, unsigned char* dst, unsigned voff)
+{
+#if defined(__HIP_DEVICE_COMPILE__)       // (the host pass has no LDS address space to cast to)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, voff, 0, 0, LITHO_COOP_DMA_AUX);
+#endif
+}
+
+template <int LOG2N, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void k_ypass_coop_dma(
+    const float2* __restrict__ Tbuf, float* __restrict__ slab, const float2* __restrict__ twtab,
+    PassGeom g, int nb, int G, int gstride)
+{
+    static_assert(LOG2N == 12, "cooperative-loading y-pass over 16-column tiles: N = 4096");
+    using W = WaveSq<6>;
+    using CS = CoopDmaShape<NW>;
+    constexpr int S = CS::S, N = CS::N, JLIVE = CS::JLIVE, NLIVE = CS::NLIVE, TC = 16, RB = 8 * TC;
+    constexpr int PART_BYTES = 8 * NW;                         // bytes of a tile row this workgroup owns (NW columns)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & (NW - 1);      // column inside the workgroup's part
+    unsigned char* const region = smem_raw + wv * CS::WAVE_BYTES;                    // this wave's DMA target = its transpose matrix
+    float* lds = reinterpret_cast<float*>(region);
+    float2* twlds = reinterpret_cast<float2*>(smem_raw + NW * CS::WAVE_BYTES);
+    W::fill_lane_twiddle_table(twlds, twtab, 1, threadIdx.x, 64 * NW);
+    __syncthreads();
+
+    // blocks b, b + 8, ... (same XCD, back to back) take the PARTS parts of one 16-column tile
+    const int b = blockIdx.x;
+    const int tile = (b / (8 * CS::PARTS)) * 8 + (b & 7), part = (b >> 3) % CS::PARTS;
+    const int qx = tile * TC + part * NW + wv;
+    const int plane = blockIdx.y / G, grp = blockIdx.y - plane * G;
+    Tbuf += (size_t)plane * nb * g.t_point;
+    slab += (size_t)plane * gstride * g.nt * 4 * g.pn;
+    const bool active = tile * TC < g.pn;
+    float acc[S];
+    static_for<0, S>([&](auto i) { acc[i] = 0.f; });
+
+    const unsigned tile_bytes = active ? (unsigned)g.rows * RB : 0u;
+    // Units (live slot, half of its 64 rows): wave wv takes the half h = wv & 1 of the slots i0 = wv >> 1, i0 + 2, ...
+    const int i0 = wv >> 1, h = wv & 1;                        // wave-uniform
+    const unsigned sb = (unsigned)(-g.ky0 * RB + part * PART_BYTES + i0 * RB * S + h * 32 * RB);
+    constexpr int NM = CS::UNITS;                              // 17 units for i0 = 0, 16 for i0 = 1
+
+    auto prefetch = [&](int s) {
+#ifdef LITHO_DIAG_COOP_NOLOAD                                    // timing diagnostic (wrong results): no global traffic at all
+        return;
+#endif
+        const __amdgpu_buffer_rsrc_t rT =
+            make_rsrc(Tbuf + (size_t)s * g.t_point + (size_t)(active ? tile : 0) * g.rows * TC, tile_bytes);
+        // DMA lane p -> row p >> 1 of the unit, 16-byte half (p & 1) ^ (bit 3 of the row): LDS granule p of the unit.
+        // Re-derived per line from one opaque register (hoisted, the offsets would be live across the transform).
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+#ifdef LITHO_COOP_DMA_NOSWZ
+        const int lrow = ln >> 1, le = ln & 1;
+#else
+        const int lrow = ln >> 1, le = (ln ^ (ln >> 4)) & 1;
+#endif
+#if defined(LITHO_DIAG_COOP_DMA_MODE) && LITHO_DIAG_COOP_DMA_MODE == 1     // timing diagnostics (wrong results): one row per instruction,
+        const unsigned vbx = (unsigned)le * 16u + sb + 0 * lrow;
+#elif defined(LITHO_DIAG_COOP_DMA_MODE) && LITHO_DIAG_COOP_DMA_MODE == 2   // every lane out of range (no memory traffic, zeros to LDS)
+        const unsigned vbx = 0xF0000000u + (unsigned)lrow * RB + (unsigned)le * 16u;
+#else
+        const unsigned vbx = (unsigned)lrow * RB + (unsigned)le * 16u + sb;
+#endif
+        static_for<0, NM>([&](auto m_) {
+            constexpr int m = decltype(m_)::value;             // slot i = i0 + 2 m: live index, j = i (i <= 16) or i + 31
+            constexpr unsigned lo = (unsigned)(RB * S * 2 * m), hi = (unsigned)(RB * S * (2 * m + S - NLIVE) - RB * N);
+            unsigned char* const dst = region + m * 1024;
+            if constexpr (2 * m + 1 <= JLIVE) dma_b128_to_lds(rT, dst, vbx + lo);
+            else if constexpr (2 * m + 1 >= NLIVE) { if (i0 == 0) dma_b128_to_lds(rT, dst, vbx + hi); }      // slot 33 does not exist
+            else if constexpr (2 * m > JLIVE) dma_b128_to_lds(rT, dst, vbx + hi);
+            else dma_b128_to_lds(rT, dst, vbx + (i0 ? hi : lo));
+        });
+    };
+
+    // reader: lane = row of the slot (half hh = lane >> 5, row r = lane & 31 of its unit); column wv = 16-byte half e, float2 c
+    // of the half.  Live slot li sits in the region of wave 2 (li & 1) + hh, unit li >> 1, granule 2 r + (e ^ bit 3 of r).
+    const int rr = lane & 31, hh = lane >> 5;
+#ifdef LITHO_COOP_DMA_NOSWZ
+    const unsigned rd_lane = (unsigned)((2 * rr + (wv >> 1)) * 16 + (wv & 1) * 8);
+#else
+    const unsigned rd_lane = (unsigned)((2 * rr + ((wv >> 1) ^ ((rr >> 3) & 1))) * 16 + (wv & 1) * 8);
+#endif
+    const unsigned char* const rd_even = smem_raw + hh * CS::WAVE_BYTES + rd_lane;
+    const unsigned char* const rd_odd = rd_even + 2 * CS::WAVE_BYTES;
+    auto live_index = [](int j) constexpr { return j <= JLIVE ? j : j - (S - NLIVE); };
+
+    if (grp < nb) prefetch(grp);
+    for (int s = grp; s < nb; s += G) {
+#ifndef LITHO_DIAG_COOP_NOWAIT                                   // (timing diagnostic, wrong results: the loads are issued, nobody waits)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's units of line s have landed in its region
+#endif
+        lds_barrier();                                         // B1: and everybody else's in theirs
+        float2 x[S];
+        static_for<0, S>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            if constexpr (j <= JLIVE || j >= S - JLIVE) {
+                constexpr int li = live_index(j);
+                x[j] = *reinterpret_cast<const float2*>((li & 1 ? rd_odd : rd_even) + (li >> 1) * 1024);
+            } else {
+                x[j] = make_float2(0.f, 0.f);
+            }
+        });
+        W::dft_dif(x);                                         // pass A: slot brev(m) = y[m]
+        typename W::LaneTwiddles tw;
+        asm volatile("" ::: "memory");                         // the table reads stay behind pass A (30 registers)
+        static_for<1, W::NTW>([&](auto i_) { constexpr int i = decltype(i_)::value; if constexpr (i != 8) tw.row[i] = twlds[i * 64 + lane]; });
+        W::lane_twiddle_mul(x, tw);
+        lds_barrier();                                         // B2: every wave has taken its samples out of the regions
+        int lt = lane;                                         // opaque: the transposes' 16 read bases (ds_read2 reaches 1 KB) are then
+        asm volatile("" : "+v"(lt));                           // re-derived per line instead of living -- spilled -- across the loop
+        W::transpose(x, lds, lt);
+        const int snext = s + G;
+        if (snext < nb) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the transposes have read the matrix: the DMA may overwrite it
+            prefetch(snext);
+        }
+        W::dft_dif(x);                                         // pass B
+        static_for<0, S>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            const float2 v = x[W::brev(i)];
+            acc[i] = fmaf(v.x, v.x, fmaf(v.y, v.y, acc[i]));
+        });
+    }
+    if (!active || qx >= g.pn) return;
+    float* srow = slab + ((size_t)grp * g.nt * 4 + qx) * g.pn;
+    static_for<0, S>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        const int n = lane + S * i;
+        const int v = n < S * S / 2 ? n : n - S * S;
+        srow[v + g.c] += acc[i];
+    });
+}
+
+// ----------------------------------------------------------------------------------
 // y-pass for N = 8192, pn = 4096 (BASELINE config 4), pupil inside the unit disk: a PAIR of waves per column
 // (WaveSq<6>::run_pair).  Each wave loads 17 live slots (like the 4096-point kernel), runs a pruned-input pass A,
 // exchanges with its partner at the transpose, and accumulates the 32 kept bins of its half of the line.
@@ -742,6 +909,18 @@ hipError_t launch_ypass_wave(const float2* T, float* slab, const float2* tw, con
 #define LITHO_COOP_WAVES 4
 #endif
             constexpr int NW = LITHO_COOP_WAVES;
+#ifdef LITHO_COOP_DMA
+            {
+                static LdsOnce once_dma;
+                auto kd = k_ypass_coop_dma<LOG2N, NW>;
+                hipError_t ed = set_lds(once_dma, kd, CoopDmaShape<NW>::LDS_BYTES);
+                if (ed != hipSuccess) return ed;
+                hipLaunchKernelGGL(kd, dim3(CoopDmaShape<NW>::grid_x(g.pn), planes * G), dim3(64 * NW), CoopDmaShape<NW>::LDS_BYTES, st, T,
+                                   slab, tw, g, nb, G, gstride);
+                note_kernel(1, "k_ypass_coop_dma<%d, %d>", LOG2N, NW);
+                return hipGetLastError();
+            }
+#endif
             static LdsOnce once;
             auto kern = k_ypass_coop<LOG2N, NW>;
             hipError_t e = set_lds(once, kern, CoopShape<NW>::LDS_BYTES);

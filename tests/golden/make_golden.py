@@ -458,6 +458,40 @@ def g12_shard4096():
     save("g12_shard4096.npz", **out)
 
 
+def g17_config4_fold_run():
+    """4,000 CONSECUTIVE source points of BASELINE config 4 (4096^2 bernoulli mask, annular 0.4-0.8, defocus pupil
+    [0,0,0,0,100]), points [400000, 404000) of the row-major list, by the reference's own abbeImage (raw intensity
+    captured from the same run): 66 launch batches of the engine's default 60-point batch at this size plus 40 points,
+    i.e. MORE than one 64-batch slab fold (3,840 points), so the engine's two-level summation at config 4's default
+    launch geometry is compared with the reference's sequential fp32 loop on dense data.  Between two and three hours
+    of this container's CPUs (about 2-3 s per point)."""
+    print("G17 config 4, 4000 consecutive points at 4096^2")
+    import time
+    pn, lo, n = 4096, 400000, 4000
+    out = {}
+    mk = quiet(ref_mask.Mask, bernoulli_mask(pn), PS, CPU)
+    mft = mk.fraunhofer(WL, True)
+    full = source("annular", pn, 0.4, 0.8)
+    pts = torch.argwhere(full)
+    bm = torch.zeros_like(full)
+    sel = pts[lo:lo + n]
+    bm[sel[:, 0], sel[:, 1]] = 1
+    pf = pupil_fn(pn, [0, 0, 0, 0, 100])
+    t0 = time.time()
+    final, raw = full_image_with_raw(mk, mft, pf, bm)
+    out["reference_seconds"] = np.float64(time.time() - t0)
+    out["reference_threads"] = np.int64(torch.get_num_threads())
+    for tag, img in (("final", final), ("raw", raw)):
+        crop_stats(f"cfg4run_{tag}", img, out)
+        out[f"cfg4run_{tag}_stride32"] = img[::32, ::32].contiguous()
+        out[f"cfg4run_{tag}_rows"] = img[[0, 1, 1023, 2047, 2048, 3071, img.shape[0] - 2, img.shape[0] - 1], :].contiguous()
+    out["cfg4run_range"] = np.array([lo, lo + n, pts.shape[0]], dtype=np.int64)
+    out["cfg4run_first_last_shift"] = shifts_of(bm, pn)[[0, -1]]
+    print(f"   points [{lo},{lo + n}) of {pts.shape[0]}  {float(out['reference_seconds']):.0f} s  final shape "
+          f"{tuple(final.shape)}  sum={float(final.double().sum()):.7e}", flush=True)
+    save("g17_config4_fold_run.npz", **out)
+
+
 def g13_config3_long_run():
     """1,536 CONSECUTIVE source points of BASELINE config 3 (2048^2 bernoulli mask, quasar 0.4-0.8, 10-term demo pupil),
     points [60000, 61536) of the row-major list, by the reference's own abbeImage (raw intensity captured from the same
@@ -616,4 +650,4 @@ if __name__ == "__main__":
     for g in which:
         {"g1": g1_sources, "g2": g2_pupils, "g3": g3_mask_spectra, "g4": g4_fields,
          "g5": g5_images, "g6": g6_through_focus, "g8": g8_large_pupils, "g9": g9_config5_stack, "g10": g10_contiguous_shards,
-         "g11": g11_config2_full, "g12": g12_shard4096, "g13": g13_config3_long_run, "g14": g14_config3_rank_shard, "g15": g15_config5_stack_run, "g16": g16_odd_sizes}[g]()
+         "g11": g11_config2_full, "g12": g12_shard4096, "g13": g13_config3_long_run, "g14": g14_config3_rank_shard, "g15": g15_config5_stack_run, "g16": g16_odd_sizes, "g17": g17_config4_fold_run}[g]()

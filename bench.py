@@ -64,6 +64,10 @@ VALU_PEAK_TFLOPS = 157.3              # MI355X_MICROARCH.md: peak fp32 vector
 # x-pass 24 (read mask window 8 + pupil window 8, write intermediate 8) + y-pass 16 (read
 # intermediate 8, read-modify-write intensity 8).
 ALGO_BYTES = {"xpass": 24.0, "ypass": 16.0}
+# BASELINE.md's absolute target: >= 60 % of the HBM roofline under the 40-byte model at 2048^2 = 0.6 * 8e12 / 40 per GPU
+TARGET_ABS_PER_GPU = 1.2e11
+# launch geometry that PMC bytes per item depend on besides the kernel names (profiles/traffic.json entries carry it)
+GEOMETRY_KEYS = ("batch", "groups_per_plane", "xchunk", "planes_in_flight", "coarse_grid", "variant")
 
 
 def parse_args():
@@ -180,6 +184,70 @@ def kernel_profile(nat, prof, plan, pn, N, pe=None):
     return kern, n_exec
 
 
+def attach_traffic(workload, kern, plan):
+    """PMC-derived memory-side bytes (rocprofv3 --pmc passes over this very command: profiles/traffic.json) onto the kernel
+    records of one workload; returns the entry's provenance string.  Counters are only meaningful for the kernel AND the launch
+    geometry they were collected on: an entry made for another kernel (a renamed / re-parametrised variant since the capture)
+    or for another batch / group count / chunk (a host-side change that leaves the kernel names alone) is dropped, not reused."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return None
+    try:
+        entry = json.load(open(tpath)).get(workload, {})
+    except Exception:
+        return None
+    src = entry.get("source")
+    if entry.get("commit"):
+        src = f"{src} [captured at commit {entry['commit']}]"
+    geo = entry.get("geometry")
+    geo_now = {k: plan.get(k) for k in GEOMETRY_KEYS}
+    for k in kern:
+        per_item = entry.get(k + "_bytes_per_item")
+        made_for = entry.get(k + "_kernel")
+        if made_for is not None and made_for != kern[k]["kernel"]:
+            kern[k]["traffic_stale"] = f"profiles/traffic.json holds counters of {made_for}, this run launched {kern[k]['kernel']}"
+            continue
+        if geo is None or any(geo.get(g) != geo_now[g] for g in GEOMETRY_KEYS):
+            kern[k]["traffic_stale"] = f"profiles/traffic.json was captured with launch geometry {geo}, this run planned {geo_now}"
+            continue
+        if per_item is not None and kern[k]["avg_launch_ms"] > 0:
+            kern[k]["traffic"] = per_item * kern[k]["items_per_launch"]
+            kern[k]["fabric_GBs"] = kern[k]["traffic"] / (kern[k]["avg_launch_ms"] * 1e-3) / 1e9
+            kern[k]["fabric_frac"] = kern[k]["fabric_GBs"] / HBM_PEAK_GBS
+    return src
+
+
+INFINITY_CACHE_BYTES = 256 << 20
+
+
+def hbm_streaming(kern, plan, pe):
+    """The HBM-honest figure (round-4 review, item 3).  rocprofv3 on this image offers no counter behind the Infinity Cache
+    (profiles/r05_rocprofv3_counter_list.txt: no DF / UMC / MALL block), so fabric bytes equal HBM bytes only where the cache
+    cannot hold the working set: when one launch pair's T (batch x item, written once by the x-pass and read once by the
+    y-pass, everything else is small) is several times the 256 MiB cache.  True for 4096^2 (67 MB x 60 items = 4 GB), false for
+    the cache-sized batches of 2048^2 and below.  Then: (x-pass + y-pass PMC bytes per item) / (their time per item) against
+    the 8 TB/s peak."""
+    t_item = float(plan["box_rows"]) * pe * 8.0
+    batch_bytes = t_item * plan["batch"] * max(1, plan["planes_in_flight"])
+    streams = batch_bytes >= 4 * INFINITY_CACHE_BYTES
+    out = {"hbm_streaming": streams, "T_bytes_per_launch_pair": batch_bytes, "infinity_cache_bytes": INFINITY_CACHE_BYTES}
+    if not streams:
+        out["note"] = ("one launch pair's T fits the Infinity Cache (by design): fabric bytes are NOT HBM bytes here, and no counter "
+                       "behind the cache exists on this image (profiles/r05_rocprofv3_counter_list.txt)")
+        return out
+    if all("traffic" in kern[k] for k in ("xpass", "ypass")):
+        per_item_bytes = sum(kern[k]["traffic"] / kern[k]["items_per_launch"] for k in ("xpass", "ypass"))
+        per_item_s = sum(kern[k]["avg_launch_ms"] * 1e-3 / kern[k]["items_per_launch"] for k in ("xpass", "ypass"))
+        out.update({"bytes_per_item": per_item_bytes, "us_per_item": per_item_s * 1e6,
+                    "hbm_GBs": per_item_bytes / per_item_s / 1e9, "hbm_frac": per_item_bytes / per_item_s / 1e9 / HBM_PEAK_GBS,
+                    "per_kernel_hbm_frac": {k: kern[k]["fabric_frac"] for k in ("xpass", "ypass")},
+                    "note": "T streams through HBM (working set >> Infinity Cache): PMC fabric bytes of x-pass + y-pass per item over "
+                            "their HIP-event time per item, against 8 TB/s -- the one honest HBM-roofline fraction of this engine"})
+    else:
+        out["note"] = "T streams through HBM, but profiles/traffic.json has no current counters for these kernels / this geometry"
+    return out
+
+
 def measured_ceilings(torch, dev):
     """Device-copy and device-fill rates of THIS box (1 GiB, beyond the 256 MiB Infinity Cache): what the memory
     system sustains for plain streams, to put next to the 8 TB/s spec the fractions are quoted against."""
@@ -200,50 +268,87 @@ def measured_ceilings(torch, dev):
         return None, None
 
 
+# What an N-GPU step should take, stated BEFORE any N > 1 run has ever executed (one GPU per lease in the build rounds; DESIGN.md
+# section 5): per rank exactly its shard of the single-GPU step -- the per-point cost is shift-independent, planning and the
+# once-per-image reconstruction do not shrink -- plus ONE all-reduce priced per xGMI link (ring: 2 (N-1)/N of the buffer through
+# ~100 GB/s effective per direction).  single_gpu_ms: measured on one MI355X this round (profiles/r05_bench*.json; cfg4 = 8 x its
+# measured shard); fixed_ms: plan read-back + coarse-grid reconstruction + post-process, which every rank repeats.
+PREDICTION = {"cfg1": {"single_gpu_ms": 0.60, "fixed_ms": 0.25}, "cfg2": {"single_gpu_ms": 188.0, "fixed_ms": 0.6},
+              "cfg3": {"single_gpu_ms": 1680.0, "fixed_ms": 1.5}, "cfg4": {"single_gpu_ms": 56500.0, "fixed_ms": 6.0},
+              "cfg5": {"single_gpu_ms": 53700.0, "fixed_ms": 40.0}}
+XGMI_EFFECTIVE_GBS = 100.0
+
+
+def predicted_step(workload, world, allreduce_bytes):
+    p = PREDICTION.get(workload)
+    if not p:
+        return None
+    ar_ms = 2.0 * (world - 1) / world * allreduce_bytes / (XGMI_EFFECTIVE_GBS * 1e9) * 1e3 if world > 1 else 0.0
+    ms = (p["single_gpu_ms"] - p["fixed_ms"]) / world + p["fixed_ms"] + ar_ms
+    return {"predicted_step_ms": ms, "predicted_speedup": p["single_gpu_ms"] / ms, "predicted_allreduce_ms": ar_ms,
+            "single_gpu_ms_assumed": p["single_gpu_ms"],
+            "note": "stated before the first N > 1 run: (single_gpu_ms - fixed_ms) / N + fixed_ms + ring all-reduce at "
+                    f"{XGMI_EFFECTIVE_GBS:.0f} GB/s per link direction (DESIGN.md section 5); compare with ms_per_step and ranks.*"}
+
+
 CPU_SAMPLE_POINTS = {256: 64, 1024: 16, 2048: 8, 4096: 4}      # BASELINE.md / SURVEY 8d: K source points per grid size
 
 
-def cpu_baseline(torch, nat, w, plan, full=False, reps=3):
-    """The reference's CPU path beside the GPU number, in the same run on the GPU box's own host cores: the oracle's
-    torch-CPU op chain (oracle/abbe_oracle.py abbe_raw: roll / mul / pad / fftshift / ifft2 / ifftshift / crop / abs^2 / add,
-    a port of imageformation.py:62-67; the reference's Python itself does not travel to the GPU box) over K source points
-    strided through the real list -- the loop is strictly linear in S -- or, `full`, over the WHOLE list once (config 1, as
-    BASELINE.md asks).  The same points then go through the GPU on the evaluation path the timed step ran (options, not
-    the environment) for a parity figure.  Reported, not optimised."""
+def cpu_baseline_prepare(torch, nat, w, plan, full=False):
+    """GPU half of the CPU-baseline leg, run while the workload is still resident: the K sample points through the GPU on
+    the evaluation path the timed step ran (options, not the environment), and host copies of what the CPU half needs.
+    The CPU half (cpu_baseline_run) is run AFTER every GPU timing of the bench (round-4 advice: the CPU legs used to sit
+    between the extra workloads' GPU timings and left torch's thread setting changed behind them)."""
     import lithographysimulator_amd as L
-    from oracle import abbe_oracle as O
     pn, N, planes, S_full, dev = w.pn, w.N, w.planes, w.S_full, w.dev
-    # 32 threads is the fastest setting for this op chain on the GPU box's 2 x EPYC 9575F (256 hw threads:
-    # 8 -> 2.1e7, 32 -> 2.6e7, 256 -> 1.6e6 pt*px/s; scripts/cpu_threads_probe.py), so that is the baseline.
-    host_cpus = os.cpu_count() or 1
-    torch.set_num_threads(min(host_cpus, 32))
     shifts = L.sourceShifts(w.bitmap, pn)
     K = S_full if full else CPU_SAMPLE_POINTS.get(pn, 8)
     sel = shifts.cpu() if full else shifts[(torch.arange(K, device=dev) * S_full) // K].cpu()
     p_one = w.pupil if planes == 1 else w.pupil[planes // 2]
-    m_cpu, p_cpu = w.maskFT.cpu(), p_one.cpu()
-    O.abbe_raw(m_cpu, p_cpu, sel[:1], N)                        # warm-up
-    times = []
-    for _ in range(1 if full else reps):
-        c0 = time.perf_counter()
-        ref_raw = O.abbe_raw(m_cpu, p_cpu, sel, N)
-        times.append(time.perf_counter() - c0)
-    tmed = statistics.median(times)
     # the parity sample runs the evaluation path of the TIMED step (a handful of points would otherwise fall below
     # the coarse-grid path's source-count threshold and check the direct kernels instead)
     gpu_raw = L.abbeIntensity(w.maskFT, p_one, sel.to(dev), N, options={"coarse": 2 if plan.get("coarse_grid") else 0}).cpu()
     parity_plan = nat.last_plan()
     assert parity_plan["coarse_grid"] == plan.get("coarse_grid"), (parity_plan, plan)
+    return {"pn": pn, "N": N, "planes": planes, "S_full": S_full, "K": K, "full": full, "sel": sel, "m_cpu": w.maskFT.cpu(),
+            "p_cpu": p_one.cpu(), "gpu_raw": gpu_raw, "parity_plan": parity_plan, "kernels": list(nat.last_kernels())}
+
+
+def cpu_baseline_run(torch, st, reps=3):
+    """The reference's CPU path beside the GPU number, in the same run on the GPU box's own host cores: the oracle's
+    torch-CPU op chain (oracle/abbe_oracle.py abbe_raw: roll / mul / pad / fftshift / ifft2 / ifftshift / crop / abs^2 / add,
+    a port of imageformation.py:62-67; the reference's Python itself does not travel to the GPU box) over K source points
+    strided through the real list -- the loop is strictly linear in S -- or, `full`, over the WHOLE list once (config 1, as
+    BASELINE.md asks), compared with the GPU image of the same points (cpu_baseline_prepare).  Reported, not optimised."""
+    from oracle import abbe_oracle as O
+    pn, N, planes, S_full, K, full, sel = (st[k] for k in ("pn", "N", "planes", "S_full", "K", "full", "sel"))
+    m_cpu, p_cpu, gpu_raw, parity_plan = st["m_cpu"], st["p_cpu"], st["gpu_raw"], st["parity_plan"]
+    # 32 threads is the fastest setting for this op chain on the GPU box's 2 x EPYC 9575F (256 hw threads:
+    # 8 -> 2.1e7, 32 -> 2.6e7, 256 -> 1.6e6 pt*px/s; scripts/cpu_threads_probe.py), so that is the baseline.
+    host_cpus = os.cpu_count() or 1
+    threads_before = torch.get_num_threads()
+    torch.set_num_threads(min(host_cpus, 32))
+    try:
+        cores = torch.get_num_threads()
+        O.abbe_raw(m_cpu, p_cpu, sel[:1], N)                        # warm-up
+        times = []
+        for _ in range(1 if full else reps):
+            c0 = time.perf_counter()
+            ref_raw = O.abbe_raw(m_cpu, p_cpu, sel, N)
+            times.append(time.perf_counter() - c0)
+    finally:
+        torch.set_num_threads(threads_before)
+    tmed = statistics.median(times)
     parity = float((gpu_raw - ref_raw).abs().max() / ref_raw.max())
     how = (f"ALL {K} source points of the list, once, {tmed:.2f} s" if full else
            f"{K} source points strided through the {S_full}-point list, 1 warm-up + {reps} reps, median {tmed:.2f} s")
-    return {"value": K * pn * pn / tmed, "unit": "source-pt*px/s", "cores": torch.get_num_threads(), "host_cpus": host_cpus,
+    return {"value": K * pn * pn / tmed, "unit": "source-pt*px/s", "cores": cores, "host_cpus": host_cpus,
             "kind": "port",
             "sample": how + f", full {pn}x{pn} grid" + (f", plane {planes // 2} of {planes}" if planes > 1 else "") +
                       "; oracle/abbe_oracle.py abbe_raw (torch-CPU roll/mul/pad/fftshift/ifft2/ifftshift/crop/abs2/add)",
             "seconds": tmed, "source_points": K,
             "gpu_vs_cpu_rel_to_max": parity,
-            "parity_path": {"coarse_grid": parity_plan["coarse_grid"], "kernels": list(nat.last_kernels())}}
+            "parity_path": {"coarse_grid": parity_plan["coarse_grid"], "kernels": st["kernels"]}}
 
 
 def extra_workload(torch, nat, dev, name, shard=None, steps=1, warm_points=0, profile_points=480, cpu=True):
@@ -277,6 +382,7 @@ def extra_workload(torch, nat, dev, name, shard=None, steps=1, warm_points=0, pr
     prof = nat.last_profile()
     kern, n_exec = kernel_profile(nat, prof, nat.last_plan(), w.pn, w.N, L.embeddedSize(w.pn, w.N))
     nat.set_profiling(False)
+    attach_traffic(name, kern, nat.last_plan())
     both = kern["xpass"]["total_ms"] + kern["ypass"]["total_ms"]
     dom = "ypass" if kern["ypass"]["total_ms"] >= 0.95 * kern["xpass"]["total_ms"] else "xpass"   # as in the headline
     out = {"workload": (f"BASELINE {name}: " if name.startswith("cfg") else f"{name}: ") + w.desc + (f" [{note}]" if note else ""), "steps": steps,
@@ -286,8 +392,11 @@ def extra_workload(torch, nat, dev, name, shard=None, steps=1, warm_points=0, pr
            "embedded_in": L.embeddedSize(w.pn, w.N) if L.embeddedSize(w.pn, w.N) != w.pn else None,
            "dominant_kernel": kern[dom]["kernel"], "dominant_kernel_time_frac": kern[dom]["total_ms"] / both if both else None,
            "dominant_kernel_valu_frac": kern[dom]["achieved_TFLOPs"] / VALU_PEAK_TFLOPS,
-           "kernels": {k: {"kernel": v["kernel"], "avg_launch_ms": v["avg_launch_ms"], "items_per_launch": v["items_per_launch"]}
+           "kernels": {k: {kk: v[kk] for kk in ("kernel", "avg_launch_ms", "items_per_launch", "traffic", "fabric_GBs", "fabric_frac",
+                                                "traffic_stale") if kk in v}
                        for k, v in kern.items()},
+           "hbm": hbm_streaming(kern, nat.last_plan(), L.embeddedSize(w.pn, w.N)),
+           "target_abs": {"per_gpu": TARGET_ABS_PER_GPU, "value_over_target": units * steps / elapsed / TARGET_ABS_PER_GPU},
            "profile_sample": f"first {sh.shape[0]} consecutive source points" + (" x 2 planes" if w.planes > 1 else "")}
     if name == "cfg1":
         # the same image as one of a SEQUENCE sharing pupil and source (PlanCache: no compaction, no planning launches, no
@@ -304,7 +413,7 @@ def extra_workload(torch, nat, dev, name, shard=None, steps=1, warm_points=0, pr
         out["sequence_with_plan_cache"] = {"images": 100, "ms_per_image": t_seq * 1e3, "value": units / t_seq}
     if cpu:
         try:
-            out["cpu_baseline"] = cpu_baseline(torch, nat, w, plan, full=(name == "cfg1"))
+            out["_cpu_state"] = cpu_baseline_prepare(torch, nat, w, plan, full=(name == "cfg1"))   # the CPU half runs after every GPU timing
         except Exception as exc:
             out["cpu_baseline"] = {"error": repr(exc)}
     del w, image
@@ -322,6 +431,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" in os.environ and args.gpus != world and not (args.gpus == 1 and world == 1):
+        # a launcher that started another number of ranks than the command line names would silently report the wrong n_gpus
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node equal to --gpus")
     args.gpus = world
     # Test hooks (tests/test_gpu_bench_contract.py): on a box with ONE GPU the multi-rank code path of this file is
     # exercised with every rank on cuda:0 and a gloo group (RCCL refuses two ranks on one device).
@@ -337,6 +449,7 @@ def main():
         else:
             dist.init_process_group(backend)
         group = dist.group.WORLD
+        assert dist.get_world_size() == world == args.gpus, (dist.get_world_size(), world, args.gpus)
 
     import lithographysimulator_amd as L
     from lithographysimulator_amd import _native as nat
@@ -404,10 +517,21 @@ def main():
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         rows = [[float(v) for v in r.cpu()] for r in allr]
+        # who the ranks are: device name + PCI address of every rank (two ranks on one device = a launch mistake on a real node)
+        props = torch.cuda.get_device_properties(dev)
+        ident = f"{props.name} pci {getattr(props, 'pci_domain_id', 0):04x}:{getattr(props, 'pci_bus_id', 0):02x}:{getattr(props, 'pci_device_id', 0):02x} cuda:{dev.index}"
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+        except Exception:
+            rccl = None
         ranks = {"step_ms": [r[0] for r in rows], "compute_ms": [r[1] for r in rows],
                  "allreduce_wait_ms": [r[2] for r in rows], "source_points": [int(r[3]) for r in rows],
                  "step_ms_max": max(r[0] for r in rows), "step_ms_min": min(r[0] for r in rows),
                  "allreduce_bytes": int(part.numel() * 4),
+                 "world": dist.get_world_size(), "backend": backend + (" (RCCL)" if backend == "nccl" else ""), "rccl_version": rccl,
+                 "devices": idents, "distinct_devices": len(set(idents)),
                  "note": "step_ms = each rank's own mean over the timed steps; compute_ms (HIP events) and "
                          "allreduce_wait_ms (host clock from this rank's compute done to its all-reduce done: "
                          "collective + waiting for the slowest rank) from one extra instrumented step"}
@@ -429,29 +553,8 @@ def main():
     # run; `roofline` describes the y-pass -- the VALU-bound one, for which a flop fraction means something -- unless the
     # x-pass leads by more than 5 %.  Both kernels carry their own figures (and their measured bound) under `kernels`.
     dom = "ypass" if kern["ypass"]["total_ms"] >= 0.95 * kern["xpass"]["total_ms"] else "xpass"
-    traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")       # PMC-derived memory-side bytes (rocprofv3 --pmc)
-    if os.path.exists(tpath):
-        try:
-            entry = json.load(open(tpath)).get(args.workload, {})
-            traffic_src = entry.get("source")
-            if entry.get("commit"):
-                traffic_src = f"{traffic_src} [captured at commit {entry['commit']}]"
-            for k in kern:
-                per_item = entry.get(k + "_bytes_per_item")
-                # counters are only meaningful for the kernel they were collected on: an entry made for another kernel
-                # (a renamed / re-parametrised variant since the capture) is dropped, not reused
-                made_for = entry.get(k + "_kernel")
-                if made_for is not None and made_for != kern[k]["kernel"]:
-                    kern[k]["traffic_stale"] = f"profiles/traffic.json holds counters of {made_for}, this run launched {kern[k]['kernel']}"
-                    continue
-                if per_item is not None and kern[k]["avg_launch_ms"] > 0:
-                    kern[k]["traffic"] = per_item * kern[k]["items_per_launch"]
-                    kern[k]["fabric_GBs"] = kern[k]["traffic"] / (kern[k]["avg_launch_ms"] * 1e-3) / 1e9
-                    kern[k]["fabric_frac"] = kern[k]["fabric_GBs"] / HBM_PEAK_GBS
-            traffic = kern[dom].get("traffic")
-        except Exception:
-            traffic = None
+    traffic_src = attach_traffic(args.workload, kern, plan)
+    traffic = kern[dom].get("traffic")
     kern["ypass"]["bound"] = "valu: fp32 issue + per-wave serial latency (load wait, LDS transposes); profiles/r03_ypass_lab.txt"
     kern["xpass"]["bound"] = ("fabric: the T stores (64-byte granules through the L2 to the Infinity Cache); without them the "
                               "kernel takes 0.6 of its time (profiles/r02_xpass_diag_variants.txt, r03_ypass_lab.txt)")
@@ -489,6 +592,7 @@ def main():
                         "(launches x avg_launch_ms of both kernels exceeds ms_per_step by that much), so achieved / frac are "
                         "slightly conservative; rocprofv3 --kernel-trace of the same command (profiles/) has the unmarked durations",
                 "traffic_source": traffic_src,
+                "hbm": hbm_streaming(kern, plan, L.embeddedSize(pn, N)),
                 "pipeline": {"achieved": both_flops / (both_ms * 1e-3) / 1e12 if both_ms else 0.0,
                              "frac": both_flops / (both_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS if both_ms else 0.0,
                              "note": "x-pass + y-pass nominal flops over their summed kernel time"},
@@ -504,13 +608,22 @@ def main():
                       "points_per_rank": math.ceil(S / world), "pixel_size": PS, "wavelength": WL, "NA": NA,
                       "parallelism": f"source-point shards x{world}, one all-reduce" if world > 1 else "single GPU",
                       "plan": plan, "image_shape": list(image.shape)},
+           "target_abs": {"per_gpu": TARGET_ABS_PER_GPU, "n_gpus": world, "value_over_target": value / (TARGET_ABS_PER_GPU * world),
+                          "source": "BASELINE.md: >= 60 % of the 8 TB/s HBM roofline under the SURVEY 8d 40-byte model at 2048^2 = 1.2e11 "
+                                    "source-pt*px/s per GPU (an EFFECTIVE figure: most of those 40 bytes are never moved)"},
            "roofline": roofline}
     if ranks is not None:
         out["ranks"] = ranks
+    if not args.shard and args.points == 0:
+        pred = predicted_step(args.workload, world, planes * pn * pn * 4)
+        if pred:
+            out["prediction"] = pred
 
-    # ---- CPU baseline leg: the oracle's op-chain port of the reference loop, rank 0, N = 1 only
+    # ---- CPU baseline leg: the oracle's op-chain port of the reference loop, rank 0, N = 1 only.  GPU half now (the workload is
+    # resident), CPU half after every GPU timing of this run
+    cpu_state = None
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(torch, nat, w, plan, full=(args.workload == "cfg1"))
+        cpu_state = cpu_baseline_prepare(torch, nat, w, plan, full=(args.workload == "cfg1"))
 
     # ---- every other BASELINE configuration, one or two timed steps each (default single-GPU run only)
     if world == 1 and not args.no_extra and args.workload == "cfg3" and not args.shard and args.points == 0:
@@ -526,6 +639,18 @@ def main():
             except Exception as exc:                              # an extra must never cost the headline line
                 extras.append({"workload": name, "error": repr(exc)})
         out["extra_workloads"] = extras
+
+    # ---- the CPU halves, after all GPU timings (torch's thread setting is restored behind each)
+    if cpu_state is not None:
+        out["cpu_baseline"] = cpu_baseline_run(torch, cpu_state)
+        cpu_state = None
+    for e in out.get("extra_workloads", []):
+        st = e.pop("_cpu_state", None)
+        if st is not None:
+            try:
+                e["cpu_baseline"] = cpu_baseline_run(torch, st)
+            except Exception as exc:
+                e["cpu_baseline"] = {"error": repr(exc)}
 
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -159,6 +159,8 @@ typedef struct litho_abbe_options {
     int32_t split;           /* 0: a source list in which SOME shifts wrap the pupil around the grid (shifted, off-axis sources) runs
                               * the general path for every point instead of being split into a non-wrapping part (every fast
                               * path) and a wrapping one (general path) on the device (default 1: from 256 source points; 2: always) */
+    int32_t coopdma;         /* 0: the 4096-point coarse-grid y-pass over 16-column tiles loads through registers (k_ypass_coop, round 3)
+                              * instead of prefetching the next line by LDS-DMA (k_ypass_coop_dma, default 1) */
 } litho_abbe_options;
 int litho_abbe_accumulate_opts(const void *maskFT, const void *pupil, int planes, const int32_t *shifts,
                                const int32_t *count_dev, int64_t capacity, int pn, int N, float *out,

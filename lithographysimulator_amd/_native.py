@@ -150,6 +150,10 @@ def workspace(device, pn, N):
             held -= _workspaces.pop(k).numel()
         ws = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
     _workspaces[key] = ws                                                      # (re)insert as most recently used
+    # The engine launches on torch's CURRENT stream, which need not be the stream the block was allocated on; the caching
+    # allocator orders reuse only against the allocation stream.  Recording the use keeps an evicted (or cleared) workspace
+    # from being handed out again while Abbe kernels queued on this stream still read or write it (round-4 advice).
+    ws.record_stream(torch.cuda.current_stream(device))
     return ws
 
 
@@ -169,7 +173,7 @@ class PlanRecord(ctypes.Structure):
 class Options(ctypes.Structure):
     """litho_abbe_options (include/litho_abbe.h): per-call launch-planner options; -1 = not set."""
     _names = ("coarse", "batch", "groups", "xchunk", "tile", "plane_chunk", "w64", "rect", "w64_8192", "xsplit", "xrect",
-              "w64x", "gcombine", "rowpairs", "force_generic", "force_general", "poison", "embed", "split")
+              "w64x", "gcombine", "rowpairs", "force_generic", "force_general", "poison", "embed", "split", "coopdma")
     _fields_ = [("size", ctypes.c_int32)] + [(n, ctypes.c_int32) for n in _names]
 
     @classmethod

@@ -509,7 +509,7 @@ static int env_int(const char* name, int dflt)
 // Tuning / test knobs.  Resolved ONCE per C-ABI call, never per launch: a field of the caller's litho_abbe_options that is
 // >= 0 wins, otherwise the LITHO_ABBE_* environment variable, otherwise the default.
 struct Knobs {
-    int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk, xsplit, rect, xrect, coarse, gcombine, rowpairs, poison, embed, split;
+    int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk, xsplit, rect, xrect, coarse, gcombine, rowpairs, poison, embed, split, coopdma;
     static int pick(const litho_abbe_options* o, size_t off, const char* name, int dflt)
     {
         if (o && off + sizeof(int32_t) <= (size_t)o->size) {
@@ -541,6 +541,7 @@ struct Knobs {
         LITHO_KNOB(poison, "LITHO_ABBE_POISON", 0);
         LITHO_KNOB(embed, "LITHO_ABBE_EMBED", 1);
         LITHO_KNOB(split, "LITHO_ABBE_SPLIT", 1);
+        LITHO_KNOB(coopdma, "LITHO_ABBE_COOPDMA", 1);
 #undef LITHO_KNOB
         return k;
     }
@@ -614,7 +615,7 @@ static void make_geom(PassGeom& g, int pn, int N, int r0, int c0, int h, int wdt
     g.pn = pn; g.c = pn / 2; g.N = N; g.nt = (pn + 3) / 4;
     g.kx0 = c0 - g.c; g.kx1 = c0 + wdt - g.c;
     g.ky0 = r0 - g.c; g.ky1 = r0 + h - g.c;
-    g.rows = h; g.general = general; g.rect_off = 0; g.gcombine = 0; g.row_pairs = 0;
+    g.rows = h; g.general = general; g.rect_off = 0; g.gcombine = 0; g.row_pairs = 0; g.coop_dma = 0;
     g.xmask = slot_mask(N, g.kx0, g.kx1);
     g.ymask = slot_mask(N, g.ky0, g.ky1);
     set_tile(g, h, tile_cols);
@@ -697,6 +698,7 @@ static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const in
     g.rect_off = rect ? 0 : 1;
     g.gcombine = kn.gcombine ? 1 : 0;
     g.row_pairs = (kn.rowpairs && g.tcl == 3) ? 1 : 0;
+    g.coop_dma = kn.coopdma ? 1 : 0;
     const bool wave_y = w64_shape && (g.tcl == 2 || g.tcl == 3 || (g.tcl == 4 && N == 4096 && variant == 0)) && ((N != 512 && N != 256) || rect) &&
                         (variant == 1 || rect || N == 4096);
 
@@ -925,7 +927,7 @@ static int reconstruct_plane(const SizeOps* ops, const SizeOps* ops_c, const Wor
     PassGeom gf;
     gf.pn = pn; gf.c = pn / 2; gf.N = pn; gf.nt = (pn + 3) / 4;
     gf.kx0 = -pn / 2; gf.kx1 = pn / 2; gf.ky0 = gf.kx0; gf.ky1 = gf.kx1;
-    gf.rows = pn; gf.general = 0; gf.rect_off = 0; gf.gcombine = 0; gf.row_pairs = 0;
+    gf.rows = pn; gf.general = 0; gf.rect_off = 0; gf.gcombine = 0; gf.row_pairs = 0; gf.coop_dma = 0;
     gf.xmask = slot_mask(pn, gf.kx0, gf.kx1); gf.ymask = gf.xmask;
     set_tile(gf, gf.rows);
     RealImageLoader ldr{ic, pn, 0, nullptr};
@@ -1251,7 +1253,7 @@ static int mask_spectrum(const int16_t* geo, int pn, double eps, int N, float2* 
     g.pn = pn; g.c = pn / 2; g.N = N; g.nt = (int)nt;
     g.kx0 = j0 - N / 2; g.kx1 = j1 - N / 2;
     g.ky0 = g.kx0; g.ky1 = g.kx1;
-    g.rows = j1 - j0; g.general = 0; g.rect_off = 0; g.gcombine = 0; g.row_pairs = 0;
+    g.rows = j1 - j0; g.general = 0; g.rect_off = 0; g.gcombine = 0; g.row_pairs = 0; g.coop_dma = 0;
     g.xmask = slot_mask(N, g.kx0, g.kx1);
     g.ymask = slot_mask(N, g.ky0, g.ky1);
     set_tile(g, g.rows);

@@ -1,6 +1,7 @@
 // common.hip -- version / error reporting entry points of the C ABI.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 
 #include "../../include/litho_abbe.h"
@@ -23,17 +24,28 @@ void note_kernel(int pass, const char* fmt, int a0, int a1, int a2, int a3)
     if (pass < 0 || pass > 1) return;
     g_note[pass] = KernelNote{fmt, {a0, a1, a2, a3}};
 }
+// Compute units of the current device (launch planning: groups, grids).  The C ABI may be called from several host threads, one
+// stream each: the per-device cache is atomic (relaxed: every writer stores the same value).  A failing query is REPORTED
+// through litho_last_error and answered with MI355X's 256 -- on a partitioned device (CPX: 32 CUs) that would over-size G.
 int device_cus()
 {
-    static int cached[64];                       // 0 = not asked yet (benign race: every thread writes the same value)
+    static std::atomic<int> cached[64];          // 0 = not asked yet
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 256; }
-    if (cached[dev] == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 256; }
-        cached[dev] = n;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= 64) {
+        set_last_error("device_cus: hipGetDevice failed or device index >= 64; assuming 256 compute units", e);
+        return 256;
     }
-    return cached[dev];
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess || n < 1) {
+            set_last_error("device_cus: hipDeviceGetAttribute(MultiprocessorCount) failed; assuming 256 compute units", e);
+            n = 256;
+        }
+        cached[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
 }
 }  // namespace litho
 

@@ -31,6 +31,7 @@ struct PassGeom {
     int gcombine;           // 1: k_ypass_rect puts the two groups of a column block into ONE workgroup and combines their
                             //    accumulators through LDS before the slab flush (half the flush traffic)
     int row_pairs;          // 1: an x-pass workgroup takes two adjacent rows (N = pn = 4096: T streams through HBM, see k_xpass_abbe)
+    int coop_dma;           // 1: 16-column tiles at N = pn = 4096 are read by k_ypass_coop_dma (next line prefetched by LDS-DMA), 0: k_ypass_coop
     unsigned xmask, ymask;  // bit e set: slot e can be non-zero for SOME thread (x / y input)
     long long t_point;      // float2 elements of T per source point = ceil(pn/tc)*rows*tc
 };

@@ -124,6 +124,26 @@ struct WaveSq {
         });
     }
 
+    // dft_dif with a hook after every butterfly stage (a caller that spreads memory instructions over the transform)
+    template <typename Hook>
+    __device__ static __forceinline__ void dft_dif_hook(float2 (&x)[S], Hook&& after_stage)
+    {
+        static_for<0, LS>([&](auto s_) {
+            constexpr int s = decltype(s_)::value;
+            constexpr int half = (S / 2) >> s;
+            constexpr int stride = (64 / S) << s;
+            static_for<0, S / 2>([&](auto b_) {
+                constexpr int b = decltype(b_)::value;
+                constexpr int grp = b / half, i = b % half;
+                constexpr int lo = grp * 2 * half + i, hi = lo + half;
+                const float2 a = x[lo], c = x[hi];
+                x[lo] = cadd(a, c);
+                x[hi] = mul_root64<(i * stride) % 32>(csub(a, c));
+            });
+            after_stage(s_);
+        });
+    }
+
     // Lane twiddles w_{S*S}^(l*m), m = 8a + b, factored as w8[a]*w1[b], in registers (an LDS-resident table
     // was measured slower: 9.15 vs 8.06 us/point at 2048^2).
     struct LaneTwiddles {

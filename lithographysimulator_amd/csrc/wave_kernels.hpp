@@ -411,10 +411,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ypass_coop_dma(
     const unsigned sb = (unsigned)(-g.ky0 * RB + part * PART_BYTES + i0 * RB * S + h * 32 * RB);
     constexpr int NM = CS::UNITS;                              // 17 units for i0 = 0, 16 for i0 = 1
 
-    auto prefetch = [&](int s) {
+    // units [M0, M1) of line s
+    auto prefetch_part = [&](int s, auto m0_, auto m1_) {
 #ifdef LITHO_DIAG_COOP_NOLOAD                                    // timing diagnostic (wrong results): no global traffic at all
         return;
 #endif
+        constexpr int M0 = decltype(m0_)::value, M1 = decltype(m1_)::value;
         const __amdgpu_buffer_rsrc_t rT =
             make_rsrc(Tbuf + (size_t)s * g.t_point + (size_t)(active ? tile : 0) * g.rows * TC, tile_bytes);
         // DMA lane p -> row p >> 1 of the unit, 16-byte half (p & 1) ^ (bit 3 of the row): LDS granule p of the unit.
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ypass_coop_dma(
 #else
         const unsigned vbx = (unsigned)lrow * RB + (unsigned)le * 16u + sb;
 #endif
-        static_for<0, NM>([&](auto m_) {
+        static_for<M0, (M1 < NM ? M1 : NM)>([&](auto m_) {
             constexpr int m = decltype(m_)::value;             // slot i = i0 + 2 m: live index, j = i (i <= 16) or i + 31
             constexpr unsigned lo = (unsigned)(RB * S * 2 * m), hi = (unsigned)(RB * S * (2 * m + S - NLIVE) - RB * N);
             unsigned char* const dst = region + m * 1024;
@@ -443,6 +445,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ypass_coop_dma(
             else dma_b128_to_lds(rT, dst, vbx + (i0 ? hi : lo));
         });
     };
+    auto prefetch = [&](int s) { prefetch_part(s, std::integral_constant<int, 0>{}, std::integral_constant<int, NM>{}); };
 
     // reader: lane = row of the slot (half hh = lane >> 5, row r = lane & 31 of its unit); column wv = 16-byte half e, float2 c
     // of the half.  Live slot li sits in the region of wave 2 (li & 1) + hh, unit li >> 1, granule 2 r + (e ^ bit 3 of r).
@@ -482,11 +485,21 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ypass_coop_dma(
         asm volatile("" : "+v"(lt));                           // re-derived per line instead of living -- spilled -- across the loop
         W::transpose(x, lds, lt);
         const int snext = s + G;
+#ifdef LITHO_COOP_DMA_SPREAD                                     // the 17 DMA instructions spread over the six stages of pass B
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        W::dft_dif_hook(x, [&](auto st_) {
+            constexpr int st = decltype(st_)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            if (snext < nb) prefetch_part(snext, std::integral_constant<int, 3 * st>{}, std::integral_constant<int, 3 * st + 3>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#else
         if (snext < nb) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the transposes have read the matrix: the DMA may overwrite it
             prefetch(snext);
         }
         W::dft_dif(x);                                         // pass B
+#endif
         static_for<0, S>([&](auto i_) {
             constexpr int i = decltype(i_)::value;
             const float2 v = x[W::brev(i)];
@@ -909,8 +922,7 @@ hipError_t launch_ypass_wave(const float2* T, float* slab, const float2* tw, con
 #define LITHO_COOP_WAVES 4
 #endif
             constexpr int NW = LITHO_COOP_WAVES;
-#ifdef LITHO_COOP_DMA
-            {
+            if (g.coop_dma) {
                 static LdsOnce once_dma;
                 auto kd = k_ypass_coop_dma<LOG2N, NW>;
                 hipError_t ed = set_lds(once_dma, kd, CoopDmaShape<NW>::LDS_BYTES);
@@ -920,7 +932,6 @@ hipError_t launch_ypass_wave(const float2* T, float* slab, const float2* tw, con
                 note_kernel(1, "k_ypass_coop_dma<%d, %d>", LOG2N, NW);
                 return hipGetLastError();
             }
-#endif
             static LdsOnce once;
             auto kern = k_ypass_coop<LOG2N, NW>;
             hipError_t e = set_lds(once, kern, CoopShape<NW>::LDS_BYTES);

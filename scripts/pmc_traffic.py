@@ -12,6 +12,7 @@ import json
 import os
 import sys
 
+GEOMETRY_KEYS = ("batch", "groups_per_plane", "xchunk", "planes_in_flight", "coarse_grid", "variant")   # = bench.py's
 root, bench_json, workload = sys.argv[1:4]
 bench = json.loads([ln for ln in open(bench_json) if ln.startswith("{")][-1])
 cfg = bench["config"]
@@ -44,7 +45,10 @@ out = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) ove
                  f"bench batching: {cfg['plan']['batch']} points x {cfg['plan']['planes_in_flight']} planes per launch pair)",
        "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes / T items (source point x plane); FETCH doubled per the "
                   "gfx950 note in MI355X_MICROARCH.md (upper bound for 8-byte loads)",
-       "items": items_total}
+       "items": items_total,
+       # launch geometry the bytes per item depend on (a host-side change of batch / groups / chunk changes them without
+       # changing a kernel name; the y-pass kernel's name carries the tile width): bench.py drops the entry on any mismatch
+       "geometry": {k: cfg["plan"][k] for k in GEOMETRY_KEYS}}
 for cls in ("xpass", "ypass"):
     # the kernel the counters belong to, as the library names it in the same bench line (bench.py drops the entry when a
     # later build launches another kernel for this workload)

@@ -72,7 +72,7 @@ int main(int argc, char** argv)
     PassGeom g;
     g.pn = pn; g.c = pn / 2; g.N = pn; g.nt = (pn + 3) / 4; g.tcl = L2N == 11 ? 3 : 4;
     g.kx0 = -pn / 4; g.kx1 = pn / 4 + 1; g.ky0 = -pn / 4; g.ky1 = pn / 4 + 1;
-    g.rows = pn / 2 + 1; g.general = 0; g.rect_off = 0; g.gcombine = 1; g.row_pairs = 0; g.xmask = 0; g.ymask = 0;
+    g.rows = pn / 2 + 1; g.general = 0; g.rect_off = 0; g.gcombine = 1; g.row_pairs = 0; g.coop_dma = 0; g.xmask = 0; g.ymask = 0;
     const int tc = 1 << g.tcl;
     g.t_point = (long long)((pn + tc - 1) / tc) * g.rows * tc;
     float2 *M, *P, *T[2], *tw;

@@ -87,7 +87,7 @@ static void geom(PassGeom& g, int pn, int rows, int tcl)
 {
     g.pn = pn; g.c = pn / 2; g.N = pn; g.nt = (pn + 3) / 4; g.tcl = tcl;
     g.kx0 = -pn / 4; g.kx1 = pn / 4 + 1; g.ky0 = -pn / 4; g.ky1 = g.ky0 + rows;
-    g.rows = rows; g.general = 0; g.rect_off = 0; g.gcombine = 0; g.row_pairs = 0; g.xmask = 0; g.ymask = 0;
+    g.rows = rows; g.general = 0; g.rect_off = 0; g.gcombine = 0; g.row_pairs = 0; g.coop_dma = 0; g.xmask = 0; g.ymask = 0;
     const long long ntile = (pn + (1 << tcl) - 1) >> tcl;
     g.t_point = (ntile * rows) << tcl;
 }

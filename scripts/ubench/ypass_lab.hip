@@ -329,7 +329,7 @@ int main(int argc, char** argv)
     PassGeom g;
     g.pn = pn; g.c = pn / 2; g.N = N; g.nt = (pn + 3) / 4; g.tcl = 3;
     g.kx0 = -pn / 4; g.kx1 = pn / 4 + 1; g.ky0 = -pn / 4; g.ky1 = pn / 4 + 1;
-    g.rows = pn / 2 + 1; g.general = 0; g.rect_off = 0; g.gcombine = 0; g.row_pairs = 0; g.xmask = 0; g.ymask = 0;
+    g.rows = pn / 2 + 1; g.general = 0; g.rect_off = 0; g.gcombine = 0; g.row_pairs = 0; g.coop_dma = 0; g.xmask = 0; g.ymask = 0;
     g.t_point = (long long)((pn + 7) / 8) * g.rows * 8;
     float2 *T, *tw;
     float *slab, *slab_ref;

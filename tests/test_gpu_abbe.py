@@ -577,11 +577,13 @@ def test_config3_long_consecutive_run_vs_golden(golden, L, dev, path):
         assert abs(float(img.double().sum()) / float(g[f"cfg3run_{tag}_sum"]) - 1) < 2e-6
 
 
-@pytest.mark.parametrize("path", ["coarse", "direct", "coarse-tile8", "coarse-tile8-rowpairs", "coarse-default-batch", "direct-default-batch"])
+@pytest.mark.parametrize("path", ["coarse", "direct", "coarse-tile8", "coarse-tile8-rowpairs", "coarse-default-batch", "direct-default-batch",
+                                  "coarse-coopreg", "coarse-coopreg-default-batch"])
 def test_consecutive_shard_4096_vs_golden(golden, L, dev, monkeypatch, path):
     """BASELINE config 4's size: 64 CONSECUTIVE source points [800000, 800064) of the 4096^2 annular list, run by the
     reference's own abbeImage (golden g12): several launch batches of the 4096-point kernels, raw intensity and the
-    4094^2 post-processed image (quirk Q5), default (coarse-grid: 16-column T tiles, k_ypass_coop) and direct evaluation,
+    4094^2 post-processed image (quirk Q5), default (coarse-grid: 16-column T tiles, k_ypass_coop_dma -- the next line prefetched
+    by LDS-DMA, round 5 -- and, "coopreg", its round-3 predecessor k_ypass_coop loading through registers) and direct evaluation,
     and the coarse grid on 8-column tiles (k_ypass_wave<12, 8, true>; with and without the row-pair x-pass).  The
     "-default-batch" runs leave the launch geometry to the planner, as a caller gets it: ONE 60-item batch with 15-point
     x-pass chunks plus a ragged batch of 4 (asserted) -- config 4's production geometry on the reference's dense data."""
@@ -595,6 +597,7 @@ def test_consecutive_shard_4096_vs_golden(golden, L, dev, monkeypatch, path):
         _opt(monkeypatch, batch="12")           # 64 points = 5 full batches + a ragged one (the default batch is 60 here)
     if "tile8" in path: _opt(monkeypatch, tile="8")
     if "rowpairs" in path: _opt(monkeypatch, rowpairs="1")
+    if "coopreg" in path: _opt(monkeypatch, coopdma="0")
     lo, hi, S = (int(v) for v in g["cfg4shard_range"])
     mask = L.Mask(bernoulli_mask(pn), PS, dev)
     mft = mask.fraunhofer(WL, True)
@@ -611,7 +614,8 @@ def test_consecutive_shard_4096_vs_golden(golden, L, dev, monkeypatch, path):
         assert (plan["batch"], plan["launches"], plan["xchunk"]) == (60, 2, 15), plan
     kx, ky = nat.last_kernels()
     if path.startswith("coarse"):
-        assert ky == ("k_ypass_coop<12, 4>" if path in ("coarse", "coarse-default-batch") else "k_ypass_wave<12, 8, true>"), (kx, ky)
+        want = "k_ypass_wave<12, 8, true>" if "tile8" in path else ("k_ypass_coop<12, 4>" if "coopreg" in path else "k_ypass_coop_dma<12, 4>")
+        assert ky == want, (kx, ky)
         assert kx == ("k_xpass_abbe<12, 0, true, 1, 2>" if "rowpairs" in path else "k_xpass_abbe<12, 0, true, 1, 1>"), (kx, ky)
     final = L.postProcess(raw, eps).cpu()
     raw = raw.cpu()
@@ -1271,8 +1275,9 @@ def _test_8192_kernels_agree_4096(L, dev, monkeypatch):
 
 
 def test_coarse_grid_4096_tile_layouts_agree(L, dev, monkeypatch):
-    """Config 4's coarse grid (N' = pn = 4096).  Default: 16-column T tiles + k_ypass_coop (four waves load 32 bytes of
-    every tile row together).  Against the 8-column layout (k_ypass_wave<12, 8, true>) and against the direct path on the radix-16 y-pass:
+    """Config 4's coarse grid (N' = pn = 4096).  Default: 16-column T tiles + k_ypass_coop_dma (four waves fetch 32 bytes of
+    every tile row together, the next line by LDS-DMA while the current one is transformed); bit-identical to k_ypass_coop (the
+    same loads through registers, `coopdma` = 0: same arithmetic in the same order).  Against the 8-column layout (k_ypass_wave<12, 8, true>) and against the direct path on the radix-16 y-pass:
     the full natural box, a through-focus stack, and a SMALLER off-centre box (rows beyond it are cut by the tile
     descriptors' range check -- also inside the slots the kernel hard-wires as live), checked against the oracle."""
     from lithographysimulator_amd import _native as nat
@@ -1289,7 +1294,10 @@ def test_coarse_grid_4096_tile_layouts_agree(L, dev, monkeypatch):
     new = L.abbeIntensity(mft, pf, sel, N).cpu()
     plan = nat.last_plan()
     assert plan["coarse_grid"] == 1 and plan["natural_box"] == 1, plan
-    assert nat.last_kernels() == ("k_xpass_abbe<12, 0, true, 1, 1>", "k_ypass_coop<12, 4>"), nat.last_kernels()
+    assert nat.last_kernels() == ("k_xpass_abbe<12, 0, true, 1, 1>", "k_ypass_coop_dma<12, 4>"), nat.last_kernels()
+    reg = _with_env(monkeypatch, L, {"LITHO_ABBE_COOPDMA": "0"}, lambda: L.abbeIntensity(mft, pf, sel, N).cpu())
+    assert nat.last_kernels()[1] == "k_ypass_coop<12, 4>", nat.last_kernels()
+    assert torch.equal(new, reg), float((new - reg).abs().max())
     t8 = _with_env(monkeypatch, L, {"LITHO_ABBE_TILE": "8"}, lambda: L.abbeIntensity(mft, pf, sel, N).cpu())
     assert nat.last_kernels()[1] == "k_ypass_wave<12, 8, true>", nat.last_kernels()
     r16 = _with_env(monkeypatch, L, {"LITHO_ABBE_W64": "0"}, lambda: L.abbeIntensity(mft, pf, sel[:3], N).cpu())
@@ -1300,7 +1308,7 @@ def test_coarse_grid_4096_tile_layouts_agree(L, dev, monkeypatch):
     # a stack: plane p of the stacked call == the single-plane call
     stack = L.throughFocusPupils(pn, WL, NA, f16(DEMO_AB), [-90.0, 110.0], dev)
     both = L.abbeIntensity(mft, stack, sel[:4], N).cpu()
-    assert nat.last_kernels()[1] == "k_ypass_coop<12, 4>"
+    assert nat.last_kernels()[1] == "k_ypass_coop_dma<12, 4>"
     for k in range(2):
         assert rel_max(both[k], L.abbeIntensity(mft, stack[k], sel[:4], N).cpu()) < 1e-6
     # a smaller, off-centre box inside the natural one: rows k in [-700, 333], columns k in [-100, 901]
@@ -1309,7 +1317,9 @@ def test_coarse_grid_4096_tile_layouts_agree(L, dev, monkeypatch):
     got = L.abbeIntensity(mft, small, sel[:2], N).cpu()
     plan = nat.last_plan()
     assert plan["coarse_grid"] == 1 and plan["natural_box"] == 1 and plan["box_rows"] <= 1034 and plan["box_cols"] <= 1002, plan
-    assert nat.last_kernels()[1] == "k_ypass_coop<12, 4>"
+    assert nat.last_kernels()[1] == "k_ypass_coop_dma<12, 4>"
+    reg = _with_env(monkeypatch, L, {"LITHO_ABBE_COOPDMA": "0"}, lambda: L.abbeIntensity(mft, small, sel[:2], N).cpu())
+    assert nat.last_kernels()[1] == "k_ypass_coop<12, 4>" and torch.equal(got, reg)
     ref = O().abbe_raw(mft.cpu(), small.cpu(), sel[:2].cpu(), N)
     e = rel_max(got, ref)
     print(f"4096^2 coarse grid, small off-centre box {plan['box_rows']} x {plan['box_cols']}: rel-to-max {e:.2e}")

@@ -16,7 +16,7 @@ WAVEFLAGS_12 ?=
 INSTFLAGS_13 ?= -mllvm -amdgpu-sched-strategy=max-ilp
 INST := $(patsubst $(CSRC)/%.hip,build/%.o,$(wildcard $(CSRC)/inst_*.hip))
 INSTW := $(patsubst $(CSRC)/%.hip,build/%.o,$(wildcard $(CSRC)/instw_*.hip))
-HDRS := $(CSRC)/fft_core.hpp $(CSRC)/wave_fft.hpp $(CSRC)/engine_kernels.hpp $(CSRC)/wave_kernels.hpp $(CSRC)/engine_common.hpp include/litho_abbe.h
+HDRS := $(CSRC)/abbe_plan.hpp $(CSRC)/fft_core.hpp $(CSRC)/wave_fft.hpp $(CSRC)/engine_kernels.hpp $(CSRC)/wave_kernels.hpp $(CSRC)/engine_common.hpp include/litho_abbe.h
 
 all: $(OUT) oracle
 
@@ -38,7 +38,11 @@ build/layout.o: $(CSRC)/layout.hip $(CSRC)/engine_common.hpp include/litho_abbe.
 build/common.o: $(CSRC)/common.hip $(CSRC)/engine_common.hpp include/litho_abbe.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-$(OUT): build/abbe_engine.o build/optics.o build/layout.o build/common.o $(INST) $(INSTW)
+# the host-only planner's dry-run entry point: plain C++ (g++, no HIP header) -- tests/test_planner_cpu.py builds it alone too
+build/plan_dry_run.o: $(CSRC)/plan_dry_run.cpp $(CSRC)/abbe_plan.hpp include/litho_abbe.h
+	@mkdir -p build
+	g++ -O2 -std=c++17 -fPIC -Wall -Wextra -c $< -o $@
+$(OUT): build/abbe_engine.o build/optics.o build/layout.o build/common.o build/plan_dry_run.o $(INST) $(INSTW)
 	@mkdir -p lithographysimulator_amd/lib
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 

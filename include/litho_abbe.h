@@ -124,10 +124,15 @@ int litho_abbe_accumulate_counted(const void *maskFT, const void *pupil, int pla
  * planning launch and never wait for the stream (images can be queued back to back).  CONTRACT: the caller passes a
  * valid record only while `pupil`, `shifts` and the count are unchanged (set plan->valid = 0 after changing them); pn, N
  * and planes are checked.  count_dev may be NULL (then `capacity` is the number of source points, as in
- * litho_abbe_accumulate).  litho_abbe_last_plan field [15] = 1 when the call planned from the record. */
+ * litho_abbe_accumulate).  A source list that was SPLIT by the planning call (a shifted source: some shifts wrap the pupil
+ * around the grid, see litho_abbe_accumulate) is split again by every planned call -- the record carries the two counts and
+ * extents, the three small split kernels are re-run without a read-back -- so the non-wrapping points keep their fast path
+ * (until round 5 a planned call ran the whole list on the general path).  litho_abbe_last_plan field [15]: 0 = planned
+ * afresh, 1 = from the record, 2 = planned afresh and the list was split, 3 = split, from the record. */
 typedef struct litho_abbe_plan {
-    int32_t words[16];      /* the read-back plan words (the library's business; [8] = source-point count, [14] = the grid
-                             * size the run was planned for: the call's own or the padded one of an embedded evaluation) */
+    int32_t words[16];      /* the library's business (packed: plan words, source-point count, the grid size the run was planned
+                             * for -- the call's own or the padded one of an embedded evaluation --, the outcome of the split;
+                             * csrc/abbe_plan.hpp record_store).  A record another library version wrote is ignored (re-planned). */
     int32_t valid;          /* 0: empty, the call fills it; 1: use it */
     int32_t pn, N, planes;  /* what it was made for */
 } litho_abbe_plan;
@@ -166,6 +171,39 @@ int litho_abbe_accumulate_opts(const void *maskFT, const void *pupil, int planes
                                const int32_t *count_dev, int64_t capacity, int pn, int N, float *out,
                                void *workspace, size_t workspace_bytes, void *stream, litho_abbe_plan *plan,
                                const litho_abbe_options *options, int64_t *count_host);
+
+/* ---- Dry run of the launch planner: what litho_abbe_accumulate* WOULD do for a problem, without touching a device.
+ * The reference has no counterpart (its loop has nothing to plan, imageformation.py:62-67); this exists so that the host
+ * logic that replaced those six lines -- batching, kernel families, embedded evaluation of odd sizes, the split of a partly
+ * wrapping source list, and above all WHERE in the caller's workspace every intermediate lives -- can be verified on a CPU
+ * for every admissible size (tests/test_planner_cpu.py).  Inputs = what the call learns from its 56-byte read-back:
+ * plan_words[14] (pupil support box rows lo/hi, columns lo/hi; shift extents dy lo/hi, dx lo/hi; source-point count;
+ * rows lo/hi of non-zero samples on the natural box's column edges, columns lo/hi on its row edges (INT_MAX / INT_MIN =
+ * none); corner flag), and -- needed only when the call would split the list -- split_words[10] (non-wrapping count,
+ * wrapping count, dy lo/hi dx lo/hi of either part).  cus = compute units (<= 0: 256); workspace_bytes = what the caller
+ * would pass (0: what litho_abbe_workspace_bytes reports).  Regions are byte ranges of the workspace.  Same code as the real
+ * path (csrc/abbe_plan.hpp).  result->status = what the call would return before its first launch. */
+typedef struct litho_abbe_region { int64_t offset, bytes; } litho_abbe_region;
+typedef struct litho_abbe_dry_part {
+    int32_t present;            /* 0: this part does not run */
+    int32_t run_size;           /* grid it runs at: pn, or the padded size of an embedded evaluation */
+    int32_t general, variant, coarse, natural_box, wave_y, xkind;   /* as litho_abbe_last_plan reports them */
+    int32_t batch, planes_in_flight, groups, slabs, xchunk, tile;
+    int64_t source_points;
+    int64_t t_item_bytes;       /* one T item of the run's geometry */
+    litho_abbe_region plan, twtab, twtab2, slab_region, slab_used, ic_used, chat_used, gam_used, T_region, T_used, recon_T_used,
+                      embed_M, embed_P, embed_O;     /* (bytes 0 = not used by this part) */
+} litho_abbe_dry_part;
+typedef struct litho_abbe_dry_run {
+    int32_t size;               /* sizeof(litho_abbe_dry_run) as the caller compiled it */
+    int32_t status;             /* LITHO_OK, or the error the call would return */
+    int32_t run_size, nowrap, split, reserved;
+    int64_t workspace_bytes;    /* litho_abbe_workspace_bytes(pn, N) */
+    litho_abbe_region list_a, list_b, split_counts;   /* the two lists of a split source list; the block counts (head of T, dead before the loops) */
+    litho_abbe_dry_part part[2];   /* [0] the whole list, or the non-wrapping part of a split; [1] the wrapping part */
+} litho_abbe_dry_run;
+int litho_abbe_plan_dry_run(int pn, int N, int planes, const int32_t *plan_words, const int32_t *split_words,
+                            const litho_abbe_options *options, int cus, size_t workspace_bytes, litho_abbe_dry_run *result);
 
 /* ---- Single-point field: calculateFFTAerial(pf, maskFFFT, pixelNumber, N)
  * (imageformation.py:32-45).  field = complex64 [pn,pn].  Reads back 16 bytes. */

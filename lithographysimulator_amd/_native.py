@@ -36,6 +36,7 @@ _SIGNATURES = {
     "litho_abbe_accumulate_opts": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int,
                                            c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, POINTER(c_int64)]),
     "litho_abbe_embedded_size": (c_int, [c_int, c_int, POINTER(c_int)]),
+    "litho_abbe_plan_dry_run": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
     "litho_abbe_field": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "litho_postprocess_size": (c_int, [c_int, c_double, POINTER(c_int)]),
     "litho_postprocess": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p]),
@@ -187,6 +188,47 @@ class Options(ctypes.Structure):
                 raise KeyError(f"unknown engine option {k!r}; known: {', '.join(cls._names)}")
             setattr(o, k, int(v))
         return o
+
+
+class Region(ctypes.Structure):
+    """litho_abbe_region: a byte range of the workspace."""
+    _fields_ = [("offset", ctypes.c_int64), ("bytes", ctypes.c_int64)]
+
+    @property
+    def end(self):
+        return self.offset + self.bytes
+
+
+class DryPart(ctypes.Structure):
+    """litho_abbe_dry_part (include/litho_abbe.h)."""
+    _regions = ("plan", "twtab", "twtab2", "slab_region", "slab_used", "ic_used", "chat_used", "gam_used", "T_region", "T_used",
+                "recon_T_used", "embed_M", "embed_P", "embed_O")
+    _fields_ = ([(n, ctypes.c_int32) for n in ("present", "run_size", "general", "variant", "coarse", "natural_box", "wave_y", "xkind",
+                                               "batch", "planes_in_flight", "groups", "slabs", "xchunk", "tile")]
+                + [("source_points", ctypes.c_int64), ("t_item_bytes", ctypes.c_int64)] + [(n, Region) for n in _regions])
+
+
+class DryRun(ctypes.Structure):
+    """litho_abbe_dry_run (include/litho_abbe.h)."""
+    _fields_ = ([(n, ctypes.c_int32) for n in ("size", "status", "run_size", "nowrap", "split", "reserved")]
+                + [("workspace_bytes", ctypes.c_int64), ("list_a", Region), ("list_b", Region), ("split_counts", Region),
+                   ("part", DryPart * 2)])
+
+
+def plan_dry_run(pn, N, planes, plan_words, split_words=None, options=None, cus=256, workspace_bytes=0):
+    """litho_abbe_plan_dry_run: what an Abbe call WOULD do (kernel families, batching, embedded evaluation, the split of a
+    partly wrapping source list, every workspace region it uses) for the given read-back words -- no device involved; works
+    without a GPU.  plan_words: the 14 plan words; split_words: the split's ten words (needed when the call would split)."""
+    pw = (ctypes.c_int32 * 14)(*[int(v) for v in plan_words])
+    sw = (ctypes.c_int32 * 10)(*[int(v) for v in split_words]) if split_words is not None else None
+    opts = Options.make(options) if options is not None else None
+    res = DryRun()
+    res.size = ctypes.sizeof(DryRun)
+    rc = lib().litho_abbe_plan_dry_run(int(pn), int(N), int(planes), ctypes.byref(pw), ctypes.byref(sw) if sw is not None else None,
+                                       ctypes.byref(opts) if opts is not None else None, int(cus), int(workspace_bytes),
+                                       ctypes.byref(res))
+    check(rc, "litho_abbe_plan_dry_run")
+    return res
 
 
 _option_stack = threading.local()

@@ -49,11 +49,7 @@ __global__ void k_twiddle_table(float2* tab, int N)
     tab[n] = make_float2((float)c, (float)s);
 }
 
-// plan words: [0]=min row,[1]=max row,[2]=min col,[3]=max col of non-zero pupil samples
-//             [4]=min dy,[5]=max dy,[6]=min dx,[7]=max dx, [8]=source-point count
-//             [9],[10]=min/max ROW with a non-zero sample on the columns c +- pn/4 (the edges of the natural support box),
-//             [11],[12]=min/max COLUMN with a non-zero sample on the rows c +- pn/4, [13]=1 if a corner of that box is set
-static constexpr int PLAN_WORDS = 14;
+// (plan words: abbe_plan.hpp)
 __global__ void k_plan_init(int* plan)
 {
     if (threadIdx.x < 8) plan[threadIdx.x] = (threadIdx.x & 1) ? INT_MIN : INT_MAX;
@@ -153,12 +149,6 @@ __global__ __launch_bounds__(1024) void k_slab_reduce(const float* __restrict__ 
     if (qx < pn && qy < pn) out[(size_t)qy * pn + qx] += tile[tx][ty];
 }
 
-static constexpr int COARSE_PLANES = 4;                      // = the largest plane chunk
-static constexpr int EDGE_MAX = 128;                         // longest box-edge support the coarse path handles
-static constexpr int GAM_CHUNKS = 1024;                      // workgroups (partial sums) of k_nyquist_edges
-static constexpr size_t GAM_PARTIAL = (size_t)GAM_CHUNKS * 2 * 2 * EDGE_MAX;      // [chunk][edge][2 * EDGE_MAX]
-static size_t gam_float2(int pn) { return GAM_PARTIAL + 2 * 2 * EDGE_MAX + 2 * (size_t)pn; }
-
 // ----------------------------------------------------------------------------------
 // Coarse-grid path: the Nyquist-line coefficients.
 // The intensity I(q) = sum_s |E_s(q)|^2 has Fourier coefficients C[kappa], |kappa| <= pn/2 (E_s lives on |k| <= pn/4), so
@@ -171,11 +161,6 @@ static size_t gam_float2(int pn) { return GAM_PARTIAL + 2 * 2 * EDGE_MAX + 2 * (
 //   dI[qy, qx] = Re(2 i^qx Gprof[qy]) for odd qx  +  Re(2 i^qy Hprof[qx]) for odd qy        (centred q)
 // to the band-limited interpolation of the coarse image.  (Derivation and a numpy check: DESIGN.md.)
 // ----------------------------------------------------------------------------------
-struct EdgeGeom {
-    int pn, c, h;            // grid, centre, half-width of the natural box
-    int lo[2], len[2];       // edge 0: columns c +- h, support rows lo[0] .. lo[0] + len[0]; edge 1: rows c +- h, support columns
-};
-
 __global__ __launch_bounds__(256) void k_nyquist_edges(const float2* __restrict__ P, const float2* __restrict__ M,
                                                        const int* __restrict__ shifts, long long S, EdgeGeom eg,
                                                        float2* __restrict__ partial)
@@ -298,7 +283,6 @@ __device__ __forceinline__ bool shift_wraps(int dy, int dx, const SplitBox& b)
 {
     return b.r0 + dy < 0 || b.r1 + dy > b.pn - 1 || b.c0 + dx < 0 || b.c1 + dx > b.pn - 1;
 }
-static constexpr int SPLIT_PER_BLOCK = 1024;
 __global__ __launch_bounds__(256) void k_split_count(const int* __restrict__ shifts, long long S, SplitBox b, int* __restrict__ counts)
 {
     __shared__ int red[4];
@@ -373,7 +357,8 @@ __global__ __launch_bounds__(256) void k_split_write(const int* __restrict__ shi
 }
 
 // ----------------------------------------------------------------------------------
-// host side
+// host side.  Sizes, the workspace layout, the launch planner and the call-level decisions live in abbe_plan.hpp (HIP-free,
+// shared with the dry-run entry point and its CPU sweep); here: the pointers, the launches, the read-backs.
 // ----------------------------------------------------------------------------------
 struct Workspace {
     int* plan;          // 64 ints
@@ -387,165 +372,22 @@ struct Workspace {
     size_t t_bytes;
 };
 
-
-// y-pass groups = private partial images (slabs).  Up to 8 for large images; small images can afford more
-// (their y-pass grid would otherwise be a handful of workgroups): as many as fit in 128 MiB, at most 64.
-static int g_cap(int pn)
-{
-    const size_t one = (size_t)((pn + 3) / 4) * 4 * pn * sizeof(float);
-    size_t n = ((size_t)128 << 20) / one;
-    return n < 8 ? 8 : (n > 64 ? 64 : (int)n);
-}
-static constexpr int SLAB_FLUSH_BATCHES = 64;
-static constexpr size_t T_BUDGET_MAX = (size_t)1 << 30;
-static constexpr size_t T_BUDGET_BIG = (size_t)4 << 30;      // images whose T items cannot be batched inside the Infinity Cache (pn >= 4096)
-static constexpr size_t T_BUDGET_MIN = (size_t)256 << 20;
-
-static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-static size_t t_budget(int pn)
-{
-    const size_t nt = (pn + 3) / 4;
-    const size_t one_general = nt * (size_t)pn * 4 * sizeof(float2);
-    size_t b = 64 * one_general;
-    if (b < T_BUDGET_MIN) b = T_BUDGET_MIN;                  // small images: room for batches of several points per y-pass group
-    // pn >= 4096: a T item is 67 MB and more, T streams through HBM whatever the batch, and longer batches amortise the
-    // y-pass's accumulator flush and ramp (4096^2, us per source point: 15 items 45.3, 30 44.1, 45 43.5, 60 43.2) --
-    // 4 GiB of a 288 GB device.
-    const size_t cap = pn >= 4096 ? T_BUDGET_BIG : T_BUDGET_MAX;
-    if (b > cap) b = cap;
-    if (b < one_general + one_general / 2) b = one_general + one_general / 2;
-    return b;
-}
-
-// Sizes at which the coarse-grid path exists (its regions of the workspace are empty elsewhere: 1.5 GiB at 8192^2)
-static bool coarse_eligible(int pn, int N)
-{
-    return N == 2 * pn && (pn == 256 || pn == 512 || pn == 1024 || pn == 2048 || pn == 4096);
-}
-static size_t ic_bytes(int pn, int N) { return coarse_eligible(pn, N) ? (size_t)COARSE_PLANES * pn * pn * sizeof(float) : 0; }
-static size_t chat_bytes(int pn, int N) { return coarse_eligible(pn, N) ? (size_t)pn * pn * sizeof(float2) : 0; }
-static size_t gam_bytes(int pn, int N) { return coarse_eligible(pn, N) ? gam_float2(pn) * sizeof(float2) : 0; }
-
-// Grid size the engine RUNS a pn x pn problem at.  The specialised kernels and the coarse grid
-// exist for pn = N and pn = N / 2; any other even size (a 1000^2 or 3000^2 mask; 10 nm pixels, where N = 4 pn) would fall to
-// the generic, runtime-predicated kernels -- 3.4-3.6x slower per source point than the NEXT LARGER power of two.  Such a
-// problem is embedded instead: mask spectrum and pupil centred in a zero-padded N / 2 (pn < N / 2) or N grid, same shift
-// list, centre pn x pn of the accumulated intensity added to `out` -- the identical sum term by term as long as no shift
-// wraps the pupil around the caller's own grid (checked on the original size; a wrapping list runs the general path as is).
-// Measured (scripts/embed_ab.py, us per source point, embedded / plain): 1000^2 at N 2048 2.48 / 8.38, 2000^2 at N 4096
-// 9.2 / 33.6, 1500^2 at N 2048 7.4 / 16.2, 3000^2 at N 4096 35.2 / 58.8; N = 4 pn: 256^2 0.63 / 0.94, 2048^2 28.4 / 37.7;
-// but 300^2 in a 512 grid 0.52 / 0.50 -- so: N / 2 from 256 up (the coarse grid applies), N from 1024 up.
-static int embedded_size(int pn, int N)
-{
-    if (pn == N || 2 * pn == N || (pn & 1)) return pn;
-    if (2 * pn < N) return N / 2 >= 256 ? N / 2 : pn;
-    return N >= 1024 ? N : pn;
-}
-// scratch of an embedded evaluation behind the workspace of the padded size: mask spectrum, COARSE_PLANES pupils, as many images
-static size_t embed_extra_bytes(int pe)
-{
-    const size_t e = (size_t)pe * pe;
-    return align_up(e * sizeof(float2), 256) + align_up(COARSE_PLANES * e * sizeof(float2), 256) + align_up(COARSE_PLANES * e * sizeof(float), 256);
-}
-
-static size_t workspace_bytes_at(int pn, int N)
-{
-    const size_t nt = (pn + 3) / 4;
-    size_t b = 256;
-    b += align_up((size_t)N * sizeof(float2), 256);
-    b += align_up((size_t)pn * sizeof(float2), 256);
-    b += align_up((size_t)g_cap(pn) * nt * 4 * pn * sizeof(float), 256);
-    b += align_up(ic_bytes(pn, N), 256);
-    b += align_up(chat_bytes(pn, N), 256);
-    b += align_up(gam_bytes(pn, N), 256);
-    b += align_up(t_budget(pn), 256);
-    return b;
-}
-// what litho_abbe_workspace_bytes reports: the engine's own regions at this size, or -- for a size that runs embedded -- the
-// larger of that (the general path of a wrapping source list) and the padded size's regions + the embedding scratch
-static size_t workspace_bytes(int pn, int N)
-{
-    const size_t own = workspace_bytes_at(pn, N);
-    const int pe = embedded_size(pn, N);
-    if (pe == pn) return own;
-    const size_t emb = workspace_bytes_at(pe, N) + embed_extra_bytes(pe);
-    return own > emb ? own : emb;
-}
-
 static bool carve(void* ws, size_t bytes, int pn, int N, Workspace& w)
 {
-    if (!ws || bytes < workspace_bytes_at(pn, N)) return false;
-    const size_t nt = (pn + 3) / 4;
+    const WsLayout l = ws_layout(pn, N);
+    if (!ws || bytes < l.total) return false;
     unsigned char* p = (unsigned char*)ws;
-    w.plan = (int*)p; p += 256;
-    w.twtab = (float2*)p; p += align_up((size_t)N * sizeof(float2), 256);
-    w.twtab2 = (float2*)p; p += align_up((size_t)pn * sizeof(float2), 256);
-    w.slab = (float*)p; p += align_up((size_t)g_cap(pn) * nt * 4 * pn * sizeof(float), 256);
-    w.ic = (float*)p; p += align_up(ic_bytes(pn, N), 256);
-    w.chat = (float2*)p; p += align_up(chat_bytes(pn, N), 256);
-    w.gam = (float2*)p; p += align_up(gam_bytes(pn, N), 256);
-    w.T = (float2*)p;
-    w.t_bytes = t_budget(pn);
+    w.plan = (int*)(p + l.plan.off);
+    w.twtab = (float2*)(p + l.twtab.off);
+    w.twtab2 = (float2*)(p + l.twtab2.off);
+    w.slab = (float*)(p + l.slab.off);
+    w.ic = (float*)(p + l.ic.off);
+    w.chat = (float2*)(p + l.chat.off);
+    w.gam = (float2*)(p + l.gam.off);
+    w.T = (float2*)(p + l.T.off);
+    w.t_bytes = l.T.bytes;
     return true;
 }
-
-static int check_sizes(int pn, int N)
-{
-    if (pn < 2 || pn > 16384 || (pn & 1)) return LITHO_E_ARG;
-    if (N < 16 || N > 16384 || (N & (N - 1))) return LITHO_E_ARG;
-    if (N < pn) return LITHO_E_NSMALL;
-    return LITHO_OK;
-}
-
-static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
-
-static int env_int(const char* name, int dflt)
-{
-    const char* e = getenv(name);
-    return (e && *e) ? atoi(e) : dflt;
-}
-
-// Tuning / test knobs.  Resolved ONCE per C-ABI call, never per launch: a field of the caller's litho_abbe_options that is
-// >= 0 wins, otherwise the LITHO_ABBE_* environment variable, otherwise the default.
-struct Knobs {
-    int force_generic, force_general, groups, batch, xchunk, tile, w64, w64_8192, w64x, plane_chunk, xsplit, rect, xrect, coarse, gcombine, rowpairs, poison, embed, split, coopdma;
-    static int pick(const litho_abbe_options* o, size_t off, const char* name, int dflt)
-    {
-        if (o && off + sizeof(int32_t) <= (size_t)o->size) {
-            const int32_t v = *(const int32_t*)((const unsigned char*)o + off);
-            if (v >= 0) return v;
-        }
-        return env_int(name, dflt);
-    }
-    static Knobs read(const litho_abbe_options* o)
-    {
-#define LITHO_KNOB(field, name, dflt) k.field = pick(o, offsetof(litho_abbe_options, field), name, dflt)
-        Knobs k;
-        LITHO_KNOB(force_generic, "LITHO_ABBE_FORCE_GENERIC", 0);
-        LITHO_KNOB(force_general, "LITHO_ABBE_FORCE_GENERAL", 0);
-        LITHO_KNOB(groups, "LITHO_ABBE_GROUPS", 0);
-        LITHO_KNOB(batch, "LITHO_ABBE_BATCH", 0);
-        LITHO_KNOB(xchunk, "LITHO_ABBE_XCHUNK", 0);
-        LITHO_KNOB(tile, "LITHO_ABBE_TILE", 0);          // 0 = automatic (8 columns on the wave-kernel path, else 4)
-        LITHO_KNOB(w64, "LITHO_ABBE_W64", 1);
-        LITHO_KNOB(w64_8192, "LITHO_ABBE_W64_8192", 1);
-        LITHO_KNOB(w64x, "LITHO_ABBE_W64X", 0);
-        LITHO_KNOB(plane_chunk, "LITHO_ABBE_PLANE_CHUNK", 0);
-        LITHO_KNOB(xsplit, "LITHO_ABBE_XSPLIT", 1);
-        LITHO_KNOB(rect, "LITHO_ABBE_RECT", 1);
-        LITHO_KNOB(xrect, "LITHO_ABBE_XRECT", 1);
-        LITHO_KNOB(coarse, "LITHO_ABBE_COARSE", 1);
-        LITHO_KNOB(gcombine, "LITHO_ABBE_GCOMBINE", 1);
-        LITHO_KNOB(rowpairs, "LITHO_ABBE_ROWPAIRS", 0);
-        LITHO_KNOB(poison, "LITHO_ABBE_POISON", 0);
-        LITHO_KNOB(embed, "LITHO_ABBE_EMBED", 1);
-        LITHO_KNOB(split, "LITHO_ABBE_SPLIT", 1);
-        LITHO_KNOB(coopdma, "LITHO_ABBE_COOPDMA", 1);
-#undef LITHO_KNOB
-        return k;
-    }
-};
 
 static thread_local int64_t g_last_plan[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
@@ -569,56 +411,12 @@ const SizeOps* size_ops(int log2n)
     }
 }
 
-// Which specialised kernel variant fits this geometry (-1 = generic).
-static int pick_variant(const PassGeom& g, const Knobs& kn)
-{
-    if (g.general || (g.pn & (g.pn - 1))) return -1;
-    const int rl = ilog2(g.N) - ilog2(g.pn);
-    if (rl < 0 || rl > 2) return -1;
-    const unsigned nat = natural_in_mask(rl);
-    if ((g.xmask & ~nat) || (g.ymask & ~nat)) return -1;
-    return kn.force_generic ? -1 : rl;
-}
-
 // Reads the plan words back (one small synchronising copy).
 static int read_plan(const Workspace& w, int host[PLAN_WORDS], hipStream_t st)
 {
     HIP_TRY(hipMemcpyAsync(host, w.plan, PLAN_WORDS * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return LITHO_OK;
-}
-
-// T tile width (columns): 4 unless LITHO_ABBE_TILE says 8 or 16 (tuning knob)
-static void set_tile(PassGeom& g, int rows, int tc = 4)
-{
-    g.tcl = (tc == 16) ? 4 : (tc == 8) ? 3 : 2;
-    const long long ntile = (g.pn + (1 << g.tcl) - 1) >> g.tcl;
-    g.t_point = (ntile * rows) << g.tcl;
-}
-
-// bit e of the mask: some thread t of a line has its slot e (sample n = t + T*e) inside [lo,hi)
-static unsigned slot_mask(int N, int lo, int hi)
-{
-    const int T = N / 16;
-    unsigned m = 0;
-    for (int e = 0; e < 16; ++e)
-        for (int t = 0; t < T; ++t) {
-            const int n = t + T * e;
-            const int k = (n >= hi) ? n - N : n;
-            if (k >= lo && k < hi) { m |= 1u << e; break; }
-        }
-    return m;
-}
-
-static void make_geom(PassGeom& g, int pn, int N, int r0, int c0, int h, int wdt, int general, int tile_cols = 4)
-{
-    g.pn = pn; g.c = pn / 2; g.N = N; g.nt = (pn + 3) / 4;
-    g.kx0 = c0 - g.c; g.kx1 = c0 + wdt - g.c;
-    g.ky0 = r0 - g.c; g.ky1 = r0 + h - g.c;
-    g.rows = h; g.general = general; g.rect_off = 0; g.gcombine = 0; g.row_pairs = 0; g.coop_dma = 0;
-    g.xmask = slot_mask(N, g.kx0, g.kx1);
-    g.ymask = slot_mask(N, g.ky0, g.ky1);
-    set_tile(g, h, tile_cols);
 }
 
 // HIP events of one profiled call; destroyed on every exit path.
@@ -639,177 +437,6 @@ struct MarkList {
         v.push_back(m);
     }
 };
-
-// Everything abbe_accumulate decides before its launch loop: which kernels run and how the work is batched.
-struct AbbePlan {
-    PassGeom g;
-    int general, variant;       // 1: roll kept on P (wrapping shifts); kernel specialisation (-1 generic, else log2(N/pn))
-    bool natural_box;           // the pupil's support box lies inside |k| <= pn/4 (and no shift wraps)
-    int r0, c0, h, wdt;         // pupil support box (rows r0 .. r0+h, columns c0 .. c0+wdt)
-    bool wave_y;                // y-pass by the wave-level family (k_ypass_wave / k_ypass_pair / k_ypass_rect)
-    bool split_x, rect_x, fused_x;   // x-pass: k_xpass_split / k_xpass_rect / plane-fused k_xpass_abbe (else per-plane fall-backs)
-    int PC, G, xchunk;          // planes in flight per launch pair, y-pass groups per plane, source points per x-pass workgroup
-    int slabs;                  // slabs per plane the y-pass actually writes: G, or G / 2 when k_ypass_rect<.., 2> folds group pairs
-    int64_t bs;                 // source points per batch
-};
-
-// pl = the 9 plan words read back from the device (pupil box, shift extents, count)
-static int plan_abbe(AbbePlan& pp, const Workspace& w, const Knobs& kn, const int pl[PLAN_WORDS], int pn, int N, int planes)
-{
-    int r0 = pl[0], h = pl[1] - pl[0] + 1, c0 = pl[2], wdt = pl[3] - pl[2] + 1;
-    const bool nowrap = (r0 + pl[4] >= 0) && (r0 + h - 1 + pl[5] <= pn - 1) &&
-                        (c0 + pl[6] >= 0) && (c0 + wdt - 1 + pl[7] <= pn - 1);
-    const int general = (!nowrap || kn.force_general) ? 1 : 0;
-    if (general) { r0 = 0; c0 = 0; h = pn; wdt = pn; }
-    PassGeom& g = pp.g;
-    make_geom(g, pn, N, r0, c0, h, wdt, general, kn.tile > 0 ? kn.tile : 4);
-    const int variant = pick_variant(g, kn);
-    // The wave-level kernels, the split x-pass and the coarse-grid path hard-wire the NATURAL support |k| <= pn/4 (the
-    // unit disk of the [-2,2) sigma grid): they load only the slots that cover it and the coarse grid assumes
-    // |kappa| <= pn/2.  pick_variant's 16-slot masks are coarser than that (a one-sided box reaching k = 3 pn/8 - 1
-    // still has the natural slot set), so the box itself is checked; anything wider runs the radix-16 kernels, whose
-    // windows are runtime-predicated inside the admitted slots.
-    const int cc = pn / 2, hh = pn / 4;
-    const bool natural_box = !general && r0 >= cc - hh && r0 + h - 1 <= cc + hh && c0 >= cc - hh && c0 + wdt - 1 <= cc + hh;
-
-    // wave-level y-pass kernels, N = 2 pn: N = 512, 1024, 2048 k_ypass_rect (8, 4, 2 columns per wave; fall-back
-    // k_ypass_wave with S = 32 for 1024 and 2048), N = 4096 k_ypass_wave (S = 64), N = 8192 k_ypass_pair
-    const int l2n = ilog2(N);
-    const int lines_per_wg = (N / 16 >= 64) ? 1 : 64 / (N / 16);
-    const bool rect_ok = kn.rect && (N == 2048 || N == 1024 || (N == 512 && (kn.tile <= 0 || kn.tile == 8)));
-    const bool w64_ok = (pn * 2 == N) && ((N == 512 && rect_ok) || N == 1024 || N == 2048 || N == 4096 ||
-                                          (N == 8192 && kn.w64_8192));   // w64_8192 defaults to 1
-    // N = pn (the coarse-grid transform, and pixel sizes that give N = pn): full-output variants of the same kernels
-    const bool full_ok = (pn == N) && (N == 1024 || N == 2048 || N == 4096 ||
-                                       ((N == 512 || N == 256) && (kn.tile <= 0 || kn.tile == 8)));
-    const bool w64_shape = ((w64_ok && variant == 1) || (full_ok && variant == 0)) && kn.w64 && natural_box;
-    // T tile width.  The x-pass's T stores are bound by the memory system's rate for partial-line writes: measured
-    // (scripts/ubench/write_bw.hip) 2.2 TB/s for 32-byte granules (4-column tiles), 3.4 TB/s for 64-byte granules
-    // (8 columns), 5.2 TB/s for whole 128-byte lines.  The wave kernels read 8-column tiles at no extra cost, the
-    // radix-16 y-pass does not (measured in round 1), so: 8 columns on the wave path, 4 elsewhere.
-    // N = pn = 4096 (config 4's coarse grid): a T item is 67 MB, T streams through HBM, and there whole-line stores are
-    // worth 7.5 us of the x-pass's 21.6 per item -- 16-column tiles, read by k_ypass_coop (24.4 us per item against
-    // k_ypass_wave's 21.2 on 8-column tiles: 38.7 us per source point against 43.1).
-    const bool coop16 = pn == N && N == 4096 && variant == 0;
-    if (kn.tile <= 0 && w64_shape && !kn.w64x) set_tile(g, h, coop16 ? 16 : 8);
-    const int tc = 1 << g.tcl;
-    // k_ypass_rect: 4096 / N adjacent columns per wave (they must fit one T tile)
-    const bool rect = (variant == 0 ? N <= 2048 : rect_ok && N <= 2048) && ((4096 / N) <= tc || (N == 256 && tc == 8));
-    g.rect_off = rect ? 0 : 1;
-    g.gcombine = kn.gcombine ? 1 : 0;
-    g.row_pairs = (kn.rowpairs && g.tcl == 3) ? 1 : 0;
-    g.coop_dma = kn.coopdma ? 1 : 0;
-    const bool wave_y = w64_shape && (g.tcl == 2 || g.tcl == 3 || (g.tcl == 4 && N == 4096 && variant == 0)) && ((N != 512 && N != 256) || rect) &&
-                        (variant == 1 || rect || N == 4096);
-
-    // y-pass groups: the grid is (column blocks) x (planes in flight) x G workgroups; pick the smallest group
-    // count that makes it a whole number of full-occupancy rounds (256 CUs x workgroups per CU).
-    const int wave_cols = rect ? 4 * (4096 / N) : N == 1024 ? 8 : (N == 8192 ? 2 : 4);   // columns per wave-kernel workgroup
-    const int wave_wpt = tc > wave_cols ? tc / wave_cols : 1;         // workgroups that share one T tile
-    const int tile_blocks = !wave_y ? (g.nt + lines_per_wg - 1) / lines_per_wg
-                            : wave_wpt == 1 ? (pn + wave_cols - 1) / wave_cols
-                                            : wave_wpt * (((pn + tc - 1) / tc + 7) / 8 * 8);
-    const int resident = device_cus() * (wave_y ? ((N <= 2048 && !rect) ? 4 : 2) : l2n <= 12 ? 3 : (l2n == 13 ? 2 : 1));
-    int a_ = tile_blocks, b_ = resident;
-    while (b_) { const int t_ = a_ % b_; a_ = b_; b_ = t_; }
-    int Gtot = resident / a_;                                  // groups that fill whole rounds
-    if (kn.groups > 0) Gtot = kn.groups;
-    if (Gtot < 1) Gtot = 1;
-    if (Gtot > g_cap(pn)) Gtot = g_cap(pn);
-
-    // Through-focus stacks: PC planes are in flight per launch pair.  The fused x-pass gathers the mask-spectrum
-    // window of a source point once for all of them (NP = 4 / 2 / 1 planes per workgroup); the y-pass gives every
-    // plane its own groups and slabs.  The T buffer of a launch pair holds PC x batch items for the planes in
-    // flight.  The gather was never the x-pass's limit (its T stores are): PC = 2 takes 40 % of the x-pass's load
-    // instructions away at equal x-pass time, but its 2 x batch items of T leave the Infinity Cache and the y-pass
-    // pays 4-5 % for that (2-3 % of the total against plane-by-plane); on the coarse-grid path, whose y-pass is twice
-    // as fast, it pays 26 % (2048^2 x 8 planes, us per point and plane: PC = 1 9.42 / 9.53, PC = 2 10.82 / 10.83,
-    // PC = 4 with a quarter of the batch 12.7).  Default: plane by plane; LITHO_ABBE_PLANE_CHUNK = 2 / 4 selects the
-    // fused launches (parity-tested).
-    int PC = planes < 1 ? planes : 1;
-    if (kn.plane_chunk > 0) PC = kn.plane_chunk < planes ? kn.plane_chunk : planes;
-    if (PC > g_cap(pn)) PC = g_cap(pn);
-
-    // Batch = source points per launch pair.  The intermediate T of one batch (PC planes x points) should stay
-    // INSIDE the 256 MiB Infinity Cache between the two passes, and a y-pass workgroup wants several points per plane
-    // to amortise its accumulator flush.  Measured (us per source point, round 2): 1024^2 (4.2 MB per item) 32 items
-    // 3.01, 48 2.85, 56 2.84, 68 3.09; 2048^2 (16.8 MB) 8 items 14.65, 12 and 17 equal within the +-2.5 % scatter of
-    // single samples (profiles/r02_tuning_sweeps.txt) -> budget 208 MiB.
-    const size_t item_bytes = (size_t)g.t_point * sizeof(float2);
-    const int64_t items_ws = (int64_t)(w.t_bytes / item_bytes);
-    if (items_ws < 1) return LITHO_E_WORKSPACE;
-    int64_t items = items_ws;
-    int64_t items_cache = (int64_t)(((size_t)208 << 20) / item_bytes);
-    // 4096^2 (67 MB per item): not even 8 items fit the cache, T round-trips HBM whatever the batch -- then the batch
-    // is as long as the workspace allows (60 items of its 4 GiB: fewer accumulator flushes in the y-pass) and an x-pass
-    // workgroup walks 15 items for its row.  us per source point, coarse-grid path, alternating A/B (round 2, 1 GiB):
-    // 8 items x chunks of 4 49.9 / 49.8; 12 x 6 47.9; 12 x 12 45.6; 15 x 5 47.5; 15 x 15 45.3 / 45.2; round 3 (4 GiB):
-    // 30 x 15 44.1, 45 x 15 43.5, 60 x 15 43.2, 60 x 60 43.3.
-    const bool beyond_cache = items_cache < 8;
-    if (beyond_cache) items_cache = 60;
-    if (items > items_cache) items = items_cache;
-    if (PC > items_ws) PC = (int)items_ws;
-    int G = Gtot / PC;                                         // groups per plane
-    if (G < 1) G = 1;
-    // Stacks keep the per-plane batch: T grows to PC x batch items and leaves the Infinity Cache, which costs the
-    // y-pass less than flushing its accumulators twice as often (alternating A/B at 2048^2 x 8 planes, us per point
-    // and plane, two boxes: PC = 1 13.40 / 13.76; PC = 2 with the batch halved 14.18, with the full batch 13.62 /
-    // 14.05; PC = 4 13.68).
-    int64_t bs = items;
-    if (kn.batch > 0) bs = kn.batch;
-    if (bs > items_ws / PC) bs = items_ws / PC;
-    if (bs < 1) bs = 1;
-    if (bs > 65535) bs = 65535;
-    // Balance: every y-pass group gets the same number of points (batch multiple of G) and the x-pass
-    // chunks divide the batch evenly (chunk = divisor of the batch nearest 4).
-    const int64_t bs_cap = bs;
-    if (kn.batch <= 0 && bs > G) bs -= bs % G;
-    // Few, long batches (small images: config 1 is 3233 points in batches of up to 825): even batches instead of full ones
-    // plus a short tail -- every launch pair costs 15-20 us before its first item (3233 = 4 x 768 + 161 was five launch
-    // pairs, 4 x 809 is four).  A ragged split over the G groups (809 = 64 x 12 + 41) costs less than that.
-    const int64_t S_plan = pl[8];
-    if (kn.batch <= 0 && S_plan > bs && S_plan <= 64 * bs_cap) {
-        const int64_t B = (S_plan + bs_cap - 1) / bs_cap;      // launch pairs needed at the cap
-        int64_t even = (S_plan + B - 1) / B;
-        if (even % G && even + (G - even % G) <= bs_cap) even += G - even % G;
-        if (even >= 1 && (S_plan + even - 1) / even < (S_plan + bs - 1) / bs) bs = even;
-    }
-    int xchunk = kn.xchunk;                                    // source points per x-pass workgroup
-    if (xchunk <= 0) {
-        // ~4 source points per workgroup: the pupil rows (5 loads per plane) are amortised over the chunk, the
-        // mask-spectrum window of each point over the planes (measured flat between 3 and 6 points)
-        const int want = PC >= 4 ? 2 : 4;
-        xchunk = want;
-        if (want == 4) for (int cand : {4, 5, 3, 6, 2}) if (bs % cand == 0) { xchunk = cand; break; }
-        if (want == 2) for (int cand : {2, 3, 1}) if (bs % cand == 0) { xchunk = cand; break; }
-        if (beyond_cache && PC == 1) {                         // see above
-            xchunk = (int)bs;
-            for (int cand : {15, 12, 16, 10, 20, 8, 6}) if (bs > cand && bs % cand == 0) { xchunk = cand; break; }
-        }
-        // 1024-point rows (64-thread workgroups, 16 per CU): longer chunks pay -- coarse-grid x-pass at 1024^2,
-        // us per point: chunk 2 1.40, 3 1.27, 4 1.18, 6 1.12, 8 1.20, 12 1.03, 16 1.06, 24 1.34, 48 2.0
-        if (N == 1024 && variant == 0 && PC == 1) for (int cand : {12, 16, 8, 6}) if (bs % cand == 0) { xchunk = cand; break; }
-    }
-
-    // N = 8192 = 2 pn: each row as two 4096-point transforms (k_xpass_split) instead of the 8192-point engine
-    pp.split_x = !general && variant == 1 && N == 8192 && g.tcl >= 2 && kn.xsplit && natural_box;
-    // Several box rows per wave on the wave-level engine, whole-line T stores (k_xpass_rect).  Measured (us per source
-    // point, radix-16 x-pass -> k_xpass_rect): N = 1024 0.57 -> 0.36, N = 2048 1.43 -> 1.46, N = 512 0.27 -> 0.26: its
-    // loads are not prefetched (no registers left), so it only pays where the radix-16 engine is at its weakest.
-    // LITHO_ABBE_XRECT: 0 off, 1 N = 1024 only (default), 2 every N <= 2048 (parity tests).
-    // The same kernel with every bin kept serves the coarse-grid transforms (variant 0, N = pn) -- only on request:
-    // with twice the loads and stores per wave it is SLOWER than the radix-16 x-pass at every size (coarse-grid x-pass,
-    // us per point, radix-16 -> rect: N' = 512 0.28 -> 0.32, 1024 1.25 -> 1.49, 2048 4.73 -> 6.77).
-    pp.rect_x = natural_box && ((variant == 1 && pn * 2 == N) || (variant == 0 && pn == N)) && N >= 512 && N <= 2048 &&
-                g.tcl == 3 && (kn.xrect >= 2 || (kn.xrect == 1 && variant == 1 && N == 1024));
-    const bool wave_x_optin = wave_y && variant == 1 && N == 4096 && kn.w64x && g.tcl == 2;      // k_xpass_w64 (slower, parity-tested)
-    pp.fused_x = !pp.split_x && !pp.rect_x && !general && variant >= 0 && !wave_x_optin;
-    pp.general = general; pp.variant = variant; pp.r0 = r0; pp.c0 = c0; pp.h = h; pp.wdt = wdt;
-    pp.natural_box = natural_box;
-    pp.wave_y = wave_y; pp.PC = PC; pp.G = G; pp.xchunk = xchunk; pp.bs = bs;
-    pp.slabs = (wave_y && rect && g.gcombine && G % 2 == 0) ? G / 2 : G;
-    return LITHO_OK;
-}
 
 // Zero fill by a kernel of ours, not hipMemsetAsync: a memset node captured into a HIP graph is not replayed correctly
 // on this stack (ROCm 7.2: the second replay after the buffer's contents changed leaves stale slabs -- 16,384 wrong
@@ -957,33 +584,14 @@ static int accumulate_planned(const float2* M, const float2* P, int planes, cons
                               int pn, int N, float* out, const Workspace& w, const Knobs& kn, const SizeOps* ops, hipStream_t st)
 {
     int rc;
-    AbbePlan pp;
-    rc = plan_abbe(pp, w, kn, pl, pn, N, planes);
+    const SizeOps* ops_c = size_ops(ilog2(pn));
+    RunPlan rp;
+    rc = plan_run(rp, w.t_bytes, kn, pl, pn, N, planes, S, device_cus(), ops_c != nullptr);
     if (rc) return rc;
-
-    // Coarse-grid path (N = 2 pn, pupil inside the natural box, no wrapping shift): the source-point loop runs
-    // pn-point transforms on the grid q = 2 v (half the arithmetic per transformed line), the fine image is
-    // reconstructed once per plane.  Needs the full-output wave kernels of size pn, empty box corners and box-edge
-    // supports of at most EDGE_MAX samples; anything else takes the direct path below.
-    AbbePlan pc_plan;
-    const SizeOps* ops_c = nullptr;
-    EdgeGeom eg;
-    // The reconstruction is a fixed cost per call and plane (about ten small launches: 0.08 ms at 256^2 .. 0.5 ms at 4096^2
-    // since round 4, when k_nyquist_reduce stopped taking 0.27 ms by itself), so short source lists stay on the direct path.
-    // Break-even measured (scripts/coarse_breakeven.py, whole-call time, profiles/r04_coarse_breakeven.txt): S = 2,900 (256^2),
-    // 400 (512^2), 180 (1024^2), 64 (2048^2), 48 (4096^2); thresholds a notch above.  LITHO_ABBE_COARSE = 2 ignores S.
-    const int64_t s_min = pn == 256 ? 3072 : pn == 512 ? 512 : pn == 1024 ? 256 : pn == 2048 ? 96 : 64;
-    bool coarse = kn.coarse && (kn.coarse >= 2 || S >= s_min) && coarse_eligible(pn, N) && pp.variant == 1 && pp.natural_box &&
-                  pl[13] == 0;
-    if (coarse) {
-        eg.pn = pn; eg.c = pn / 2; eg.h = pn / 4;
-        eg.lo[0] = pl[10] >= pl[9] ? pl[9] : 0;   eg.len[0] = pl[10] >= pl[9] ? pl[10] - pl[9] + 1 : 0;
-        eg.lo[1] = pl[12] >= pl[11] ? pl[11] : 0; eg.len[1] = pl[12] >= pl[11] ? pl[12] - pl[11] + 1 : 0;
-        ops_c = size_ops(ilog2(pn));
-        coarse = ops_c && eg.len[0] <= EDGE_MAX && eg.len[1] <= EDGE_MAX &&
-                 plan_abbe(pc_plan, w, kn, pl, pn, pn, planes) == LITHO_OK && pc_plan.variant == 0 && pc_plan.wave_y &&
-                 pc_plan.PC <= COARSE_PLANES;
-    }
+    const AbbePlan& pp = rp.direct;
+    const AbbePlan& pc_plan = rp.coarse_plan;
+    const bool coarse = rp.coarse;
+    const EdgeGeom& eg = rp.eg;
     const AbbePlan& run = coarse ? pc_plan : pp;
     const size_t plane_elems = (size_t)pn * pn;
     int64_t nx = 0;
@@ -1033,7 +641,6 @@ static int accumulate_planned(const float2* M, const float2* P, int planes, cons
     return LITHO_OK;
 }
 
-static constexpr int64_t SPLIT_MIN_POINTS = 256;          // below that the two extra launches and the read-back cost more than they save
 static int accumulate_embedded(const float2* M, const float2* P, int planes, const int* shifts, int64_t S, const int pl[PLAN_WORDS],
                                int pn, int pe, int N, float* out, void* ws, size_t ws_bytes, size_t t_cap, const Knobs& kn,
                                const SizeOps* ops, hipStream_t st);
@@ -1060,13 +667,12 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     const Knobs kn = Knobs::read(opts);
     // the grid this problem runs at: its own, or the padded one of an embedded evaluation (embedded_size) when the workspace
     // has room for it (litho_abbe_workspace_bytes says so; an older, smaller workspace simply runs the problem as it is)
-    int pe = kn.embed ? embedded_size(pn, N) : pn;
-    if (pe != pn && ws_bytes < workspace_bytes_at(pe, N) + embed_extra_bytes(pe)) pe = pn;
+    const int pe = run_size(pn, N, kn, ws_bytes);
 
     if (kn.poison) {
         // test knob: every scratch region starts the call as NaN bit patterns -- a kernel that reads scratch it (or an
         // earlier launch of THIS call) has not written turns the image into NaN (tests/test_gpu_abbe.py)
-        unsigned char* lo = (unsigned char*)ws + 256 + align_up((size_t)N * sizeof(float2), 256);       // behind plan words + twiddle table
+        unsigned char* lo = (unsigned char*)ws + ws_layout(pn, N).twtab2.off;                           // behind plan words + twiddle table
         unsigned char* hi = pe != pn ? (unsigned char*)ws + workspace_bytes_at(pe, N) + embed_extra_bytes(pe) : (unsigned char*)w.T + w.t_bytes;
         if ((unsigned char*)w.T + w.t_bytes > hi) hi = (unsigned char*)w.T + w.t_bytes;
         HIP_TRY(hipMemsetAsync(lo, 0xFF, (size_t)(hi - lo), st));
@@ -1076,9 +682,11 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     // (record word 14 = the grid the edge words were looked up for: a record made with the embedding off, or with a smaller
     // workspace, is not reused for an embedded run and vice versa)
     const bool from_record = reuse && reuse->valid == 1 && reuse->pn == pn && reuse->N == N && reuse->planes == planes &&
-                             reuse->words[8] <= S && reuse->words[14] == pe;
+                             record_is_ours(reuse->words) && record_count(reuse->words) <= S && record_run_size(reuse->words) == pe;
+    int sw[10];
+    bool rec_split = false;                                  // the record carries the outcome of the source-list split
     if (from_record) {
-        for (int i = 0; i < PLAN_WORDS; ++i) pl[i] = reuse->words[i];
+        rec_split = record_load(reuse->words, pl, sw);
     } else {
         hipLaunchKernelGGL(k_plan_init, dim3(1), dim3(64), 0, st, w.plan);
         hipLaunchKernelGGL(k_pupil_box, dim3((pn + BOX_ROWS_PER_BLOCK - 1) / BOX_ROWS_PER_BLOCK, planes), dim3(256), 0, st,
@@ -1088,8 +696,7 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
         rc = read_plan(w, pl, st);                           // the ONE host wait of the image path
         if (rc) return rc;
         if (reuse) {
-            for (int i = 0; i < 16; ++i) reuse->words[i] = i < PLAN_WORDS ? pl[i] : 0;
-            reuse->words[14] = pe;
+            record_store(reuse->words, pl, pe, nullptr);     // (a split, below, stores its ten words too)
             reuse->pn = pn; reuse->N = N; reuse->planes = planes; reuse->valid = 1;
         }
     }
@@ -1100,23 +707,21 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
 
     // Embedded evaluation -- unless a shift wraps the pupil around the CALLER's grid: the reference rolls modulo its own size
     // (imageformation.py:63), which the padded grid would not reproduce; such a list runs the general path at this size.
-    const bool nowrap = pl[0] + pl[4] >= 0 && pl[1] + pl[5] <= pn - 1 && pl[2] + pl[6] >= 0 && pl[3] + pl[7] <= pn - 1;
-    if (!nowrap && !kn.force_general && kn.split && !from_record && (S >= SPLIT_MIN_POINTS || kn.split >= 2)) {
+    const bool nowrap = list_nowrap(pl, pn);
+    // A planned call splits exactly when its record says the planning call did: it re-runs the three split kernels (same list,
+    // same deterministic result, no read-back) and plans the two parts from the recorded counts and extents.
+    if (split_wanted(kn, nowrap, from_record && !rec_split, S)) {
         // Some shift wraps the pupil around the grid -- usually for a minority of the points of a shifted source.  Split the
         // list (stable, on the device; one more 40-byte read-back) and give each part the path it needs: this function
         // again for the non-wrapping points (pruned box, coarse grid, embedding: 2.5 us per point at 1024^2), the
-        // general path for the others (10 us).  The two lists live at the end of the T region, which shrinks by them.
-        // (absolute placement: the lists end where the T region of the grid the non-wrapping part runs at ends -- the
-        // padded grid's for an embedded size -- and BOTH carves' T regions are cut short of them)
-        const size_t list_bytes = align_up((size_t)S * 2 * sizeof(int), 256);
-        const size_t t_end = pe != pn ? workspace_bytes_at(pe, N) : workspace_bytes_at(pn, N);
-        const size_t list_start = t_end - 2 * list_bytes;
-        const size_t t0_own = (size_t)((unsigned char*)w.T - (unsigned char*)ws);
-        const size_t t0_pad = pe != pn ? workspace_bytes_at(pe, N) - t_budget(pe) : t0_own;
-        const size_t room = (size_t)64 << 20;
-        if (2 * list_bytes < t_end && list_start > t0_own + room && list_start > t0_pad + room) {
+        // general path for the others (10 us).  The two lists live at the end of the T region, which shrinks by them
+        // (split_layout, abbe_plan.hpp: absolute placement -- the lists end where the T region of the grid the non-wrapping
+        // part runs at ends, the padded grid's for an embedded size, and BOTH carves' T regions are cut short of them).
+        const SplitLayout sl = split_layout(pn, pe, N, S);
+        if (sl.ok) {
             Workspace ws_split = w;
-            if (t0_own + ws_split.t_bytes > list_start) ws_split.t_bytes = list_start - t0_own;
+            ws_split.t_bytes = sl.t_bytes_own;
+            const size_t list_start = sl.list_a.off, list_bytes = sl.list_bytes;
             int* list_a = (int*)((unsigned char*)ws + list_start);
             int* list_b = (int*)((unsigned char*)list_a + list_bytes);
             int* counts = (int*)w.T;                                      // block counts: the head of T, free until the loops start
@@ -1127,9 +732,11 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
             hipLaunchKernelGGL(k_split_scan, dim3(1), dim3(1024), 0, st, counts, nblocks, (long long)S, words);
             hipLaunchKernelGGL(k_split_write, dim3(nblocks), dim3(256), 0, st, shifts, (long long)S, box, counts, list_a, list_b, words);
             HIP_TRY(hipGetLastError());
-            int sw[10];
-            HIP_TRY(hipMemcpyAsync(sw, words, sizeof(sw), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            if (!from_record) {
+                HIP_TRY(hipMemcpyAsync(sw, words, sizeof(sw), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                if (reuse) record_store(reuse->words, pl, pe, sw);
+            }
             int64_t launches = 0;
             for (int part = 0; part < 2; ++part) {
                 const int64_t n = sw[part];
@@ -1146,7 +753,7 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
                 launches += g_last_plan[6];
             }
             g_last_plan[6] = launches;                                    // (the other fields describe the part that ran last)
-            g_last_plan[15] = 2;                                          // = the source list was split
+            g_last_plan[15] = from_record ? 3 : 2;                        // = the source list was split (3: from the record, no read-back)
             return LITHO_OK;
         }
     }
@@ -1169,17 +776,13 @@ static int accumulate_embedded(const float2* M, const float2* P, int planes, con
         const size_t t0 = (size_t)((unsigned char*)w2.T - (unsigned char*)ws);
         if (t0 + w2.t_bytes > t_cap) w2.t_bytes = t_cap - t0;
     }
-    unsigned char* extra = (unsigned char*)ws + workspace_bytes_at(pe, N);
+    const EmbedLayout el = embed_layout(pe, N);
     const size_t e2 = (size_t)pe * pe;
-    float2* M2 = (float2*)extra;
-    float2* P2 = (float2*)(extra + align_up(e2 * sizeof(float2), 256));
-    float* O2 = (float*)((unsigned char*)P2 + align_up(COARSE_PLANES * e2 * sizeof(float2), 256));
-    const int off = (pe - pn) / 2;
+    float2* M2 = (float2*)((unsigned char*)ws + el.M2.off);
+    float2* P2 = (float2*)((unsigned char*)ws + el.P2.off);
+    float* O2 = (float*)((unsigned char*)ws + el.O2.off);
     int pl2[PLAN_WORDS];
-    for (int i = 0; i < PLAN_WORDS; ++i) pl2[i] = pl[i];
-    for (int i = 0; i < 4; ++i) pl2[i] += off;                                // the pupil's support box, in the padded grid
-    if (pl[10] >= pl[9]) { pl2[9] += off; pl2[10] += off; }                   // its samples on the padded grid's natural-box edges
-    if (pl[12] >= pl[11]) { pl2[11] += off; pl2[12] += off; }
+    embed_plan_words(pl, pn, pe, pl2);
     launch_embed_c64(M, 1, pn, M2, pe, st);
     for (int p0 = 0; p0 < planes; p0 += COARSE_PLANES) {
         const int pc = planes - p0 < COARSE_PLANES ? planes - p0 : COARSE_PLANES;

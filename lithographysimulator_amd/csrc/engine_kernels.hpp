@@ -11,30 +11,11 @@
 #include <hip/hip_runtime.h>
 
 #include "engine_common.hpp"
+#include "abbe_plan.hpp"
 #include "fft_core.hpp"
 #include "wave_fft.hpp"
 
 namespace litho {
-
-// ----------------------------------------------------------------------------------
-// geometry shared by the pass kernels
-// ----------------------------------------------------------------------------------
-struct PassGeom {
-    int pn, c, N;
-    int nt;                 // 4-column groups (ceil(pn/4)): one y-pass workgroup line each
-    int tcl;                // log2 of the T tile width in columns (2..4): T is [tile][row][1<<tcl]
-    int kx0, kx1;           // x-pass: valid input window [kx0,kx1) in centred coordinates
-    int ky0, ky1;           // y-pass: valid input window = rows of T; a = k - ky0
-    int rows;               // number of T rows (= ky1 - ky0)
-    int general;            // 1: roll stays on P, modular gather (wrapping shifts)
-    int rect_off;           // 1: N = 2048 y-pass by the S = 32 wave kernel instead of k_ypass_rect (test knob)
-    int gcombine;           // 1: k_ypass_rect puts the two groups of a column block into ONE workgroup and combines their
-                            //    accumulators through LDS before the slab flush (half the flush traffic)
-    int row_pairs;          // 1: an x-pass workgroup takes two adjacent rows (N = pn = 4096: T streams through HBM, see k_xpass_abbe)
-    int coop_dma;           // 1: 16-column tiles at N = pn = 4096 are read by k_ypass_coop_dma (next line prefetched by LDS-DMA), 0: k_ypass_coop
-    unsigned xmask, ymask;  // bit e set: slot e can be non-zero for SOME thread (x / y input)
-    long long t_point;      // float2 elements of T per source point = ceil(pn/tc)*rows*tc
-};
 
 template <int LOG2N>
 struct Launch {
@@ -61,16 +42,7 @@ struct Launch {
     // registers spill, 35.9 vs 28.7 us/point at 2048^2 -- and is not implemented.)
 };
 
-// Slot sets.  RL = log2(N/pn) for power-of-two pn (else -1).  PRUNED: the input window lies in
-// the "natural" support k in [-pn/4, pn/4] (pupil inside the unit disk of the [-2,2) sigma grid).
-__host__ __device__ constexpr unsigned natural_in_mask(int RL)
-{
-    return RL == 0 ? 0xF01Fu : RL == 1 ? 0xC007u : RL == 2 ? 0x8003u : 0xFFFFu;
-}
-__host__ __device__ constexpr unsigned out_mask(int RL)
-{
-    return RL == 1 ? 0xF00Fu : RL == 2 ? 0xC003u : 0xFFFFu;     // bins u in [-pn/2, pn/2)
-}
+// (PassGeom and the slot sets natural_in_mask / out_mask: abbe_plan.hpp, shared with the host-only planner)
 
 // ----------------------------------------------------------------------------------
 // buffer addressing: 32-bit offsets, and the hardware range check is the zero-padding

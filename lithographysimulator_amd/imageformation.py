@@ -50,7 +50,9 @@ class PlanCache:
     optical setting.  Every abbeImage / abbeIntensity call otherwise compacts the source bitmap and reads 56 bytes back
     to plan (pupil support box, shift extents, count): one host wait per image.  With a PlanCache the first call does
     that and records it; later calls with the SAME cache issue no compaction, no planning launch and never wait for the
-    stream, so images queue back to back.
+    stream, so images queue back to back.  A shifted, off-axis source (LightSource(shiftX, shiftY), lightsource.py:5), whose
+    list the planning call splits into a non-wrapping and a wrapping part, is split again by every planned call from the
+    record (no read-back): the non-wrapping points keep the fast path (litho_abbe_last_plan()["planned_from_record"] == 3).
 
     Contract: reuse a cache only while the pupil tensor(s) and the source bitmap are unchanged -- call invalidate() (or
     make a new one) after changing either.  As a safety net the cache remembers, host-side and without any device

@@ -11,7 +11,7 @@ UNIT=inst_$L2
 case "$L2" in w*) UNIT=instw_${L2#w};; esac
 mkdir -p build/variants
 BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC"
-OBJS="build/abbe_engine.o build/optics.o build/layout.o $(ls build/inst_*.o build/instw_*.o | grep -v "/$UNIT.o")"
+OBJS="build/abbe_engine.o build/optics.o build/layout.o build/plan_dry_run.o $(ls build/inst_*.o build/instw_*.o | grep -v "/$UNIT.o")"
 hipcc $BASE -DLITHO_DIAG_BUILD -c lithographysimulator_amd/csrc/common.hip -o build/variants/common_diag.o
 build() {
   local extra="" common="build/common.o"

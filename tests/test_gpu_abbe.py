@@ -785,7 +785,7 @@ def test_plan_cache_notices_another_pupil_or_source(L, dev):
     The cache now remembers which tensors it was made for (address, shape, version counter -- host-side only) and plans
     afresh; unchanged tensors keep the no-wait path; plan_cache with group= is refused.  (planned_from_record: 0 = planned
     afresh, 1 = from the record, 2 = planned afresh and the source list split -- the wide pupil wraps for part of the second
-    source's points.)"""
+    source's points --, 3 = split again from the record.)"""
     from lithographysimulator_amd import _native as nat
     from lithographysimulator_amd.synthetic import bernoulli_mask
     pn = 256
@@ -806,12 +806,14 @@ def test_plan_cache_notices_another_pupil_or_source(L, dev):
     assert nat.last_plan()["planned_from_record"] != 1 and torch.equal(got, img(wide, bm))
     assert not torch.equal(got, img(pf, bm))
     got = img(wide, bm2, plan_cache=cache)                                                       # another source bitmap
-    assert nat.last_plan()["planned_from_record"] != 1 and cache.S == int(bm2.sum()) and torch.equal(got, img(wide, bm2))
-    img(wide, bm2, plan_cache=cache)
-    assert nat.last_plan()["planned_from_record"] == 1
+    assert nat.last_plan()["planned_from_record"] not in (1, 3) and cache.S == int(bm2.sum()) and torch.equal(got, img(wide, bm2))
+    again = img(wide, bm2, plan_cache=cache)
+    # (3 = from the record AND split again on the device: the wide pupil wraps for part of bm2's points -- since round 5 a planned
+    # call keeps the split of its planning call instead of running every point on the general path -- and gives the same bits)
+    assert nat.last_plan()["planned_from_record"] == 3 and torch.equal(again, got)
     wide[pn // 2 + pn // 4 + 5, pn // 2] = 1.0                                                   # in-place edit, same tensor
     got = img(wide, bm2, plan_cache=cache)
-    assert nat.last_plan()["planned_from_record"] != 1 and torch.equal(got, img(wide, bm2))
+    assert nat.last_plan()["planned_from_record"] not in (1, 3) and torch.equal(got, img(wide, bm2))
     # the explicit-list form
     eps, N = mk.calculateEpsilonN(mk.deltaK, PS, WL)
     sh, sh2 = L.sourceShifts(bm, pn), L.sourceShifts(bm2, pn)
@@ -1434,3 +1436,19 @@ def test_largest_size_8192_self_consistent(L, dev, monkeypatch):
     assert float(first.double().sum()) <= float(N) ** 2 * float((A.abs().double() ** 2).sum()) * (1 + 1e-5)
     img = L.postProcess(ref, eps)
     assert img.shape == (8192, 8192)                     # 8192 -> 8192
+    # One source point against the ORACLE at this size (round-4 review, weak 1d): the float64 closed form of the reference's
+    # chain (oracle.centred_dft_matrix: E = F A F^T with A = roll(P) * M; pinned against the op chain by the CPU tests) on 24
+    # whole image rows spread over the grid -- a full 8192^2 float64 image would take the host minutes and 10 GB, the rows 3 GB.
+    o = O()
+    F = o.centred_dft_matrix(pn, N)
+    dy, dx = (int(v) for v in shifts[1].tolist())
+    A = (torch.roll(pf.cpu(), shifts=(dy, dx), dims=(0, 1)) * mft.cpu()).to(torch.complex128)
+    rows = torch.tensor([0, 1, 2, 1023, 2047, 2048, 3000, 4094, 4095, 4096, 4097, 4098, 5000, 6143, 6144, 7000, 7777, 8000, 8100, 8188, 8189,
+                         8190, 8191, 4321])
+    E = (F[rows] @ A) @ F.T
+    want = E.real ** 2 + E.imag ** 2
+    got = second.cpu()[rows].double()
+    scale = float(second.max())
+    e = float((got - want).abs().max() / scale)
+    print(f"8192^2, one source point, 24 rows against the float64 closed form: rel-to-max {e:.2e} (row maxima up to {float(want.max()) / scale:.2f} of the image maximum)")
+    assert e < TOL_IMAGE_MAX and float(want.max()) > 0.2 * scale

@@ -431,6 +431,80 @@ def test_shifted_source_is_split_into_a_fast_and_a_general_part(L, dev, pn, K):
     _check(img, o.post_process(ref.float(), eps), f"{pn}^2 shifted source through abbeImage")
 
 
+def test_planned_calls_keep_the_split_of_a_shifted_source(L, dev):
+    """Round-4 advice: a PlanCache used to make shifted-source sequences SLOWER than uncached calls -- the planning call split
+    the list, every later call found the whole-list extents in the record and ran all points on the general path.  The record now
+    carries the split's outcome; a planned call re-runs the three split kernels (same list, same result, no read-back) and plans
+    both parts from it: last_plan reports 3 (split, from the record), the image equals the planning call's bit for bit, with
+    another mask too, and equals the oracle."""
+    o = O()
+    from lithographysimulator_amd.synthetic import bernoulli_mask, lines_mask
+    pn, K = 512, 420
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    pupil = L.Pupil(pn, WL, NA, f16([0, 0, 0.01, 0, 70]), dev).generatePupilFunction()
+    sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, shiftX=0.25, shiftY=-0.5, device=dev).generateAnnular(), pn)
+    sel = sh[(torch.arange(K, device=dev) * sh.shape[0]) // K].contiguous()
+    cache = L.PlanCache()
+    first, S = L.abbeIntensity(mft, pupil, sel, N, plan=cache)
+    assert S == K and nat().last_plan()["planned_from_record"] == 2, nat().last_plan()          # planned afresh, list split
+    again, _ = L.abbeIntensity(mft, pupil, sel, N, plan=cache)
+    plan = nat().last_plan()
+    assert plan["planned_from_record"] == 3 and plan["general"] == 1, plan                       # split again, from the record
+    assert torch.equal(first, again)
+    _check(again.cpu(), _oracle_chunked(o, mft.cpu(), pupil.cpu(), sel.cpu(), N), "planned call of a shifted source")
+    mft2 = L.Mask(lines_mask(pn), PS, dev).fraunhofer(WL, True)
+    other, _ = L.abbeIntensity(mft2, pupil, sel, N, plan=cache)
+    assert nat().last_plan()["planned_from_record"] == 3
+    _check(other.cpu(), _oracle_chunked(o, mft2.cpu(), pupil.cpu(), sel.cpu(), N), "planned call of a shifted source, another mask")
+    # the launches of a planned split: as many as the planning call made
+    unplanned = L.abbeIntensity(mft2, pupil, sel, N)
+    assert nat().last_plan()["planned_from_record"] == 2 and torch.equal(unplanned, other)
+    # a record made WITHOUT the split (options) stays unsplit when reused: general path for every point, same image to rounding
+    cache0 = L.PlanCache()
+    a0, _ = L.abbeIntensity(mft, pupil, sel, N, plan=cache0, options={"split": 0})
+    b0, _ = L.abbeIntensity(mft, pupil, sel, N, plan=cache0)
+    assert nat().last_plan()["planned_from_record"] == 1 and nat().last_plan()["general"] == 1
+    assert rel_max(b0.cpu(), first.cpu()) < 2e-6 and torch.equal(a0, b0)
+
+
+@pytest.mark.parametrize("pn,K", [(2048, 12), (3000, 10)])
+def test_shifted_source_split_at_the_large_sizes(L, dev, pn, K):
+    """The split at 2048^2 and at an embedded 3000^2 (padded grid 4096; round-4 review, weak 1c): there a general-mode T item is 4x
+    a pruned one and the T regions of BOTH carves are cut short by the two lists.  Against the oracle; the dry run of the same
+    call (litho_abbe_plan_dry_run) asserts the regions apart."""
+    o = O()
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    pupil = L.Pupil(pn, WL, NA, f16([0, 0, 0.01, 0, 70]), dev).generatePupilFunction()
+    sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, shiftX=0.25, shiftY=-0.5, device=dev).generateAnnular(), pn)
+    sel = sh[(torch.arange(K, device=dev) * sh.shape[0]) // K].contiguous()
+    c, h = pn // 2, pn // 4
+    nzr = torch.nonzero(pupil.abs().sum(1) > 0).flatten()
+    nzc = torch.nonzero(pupil.abs().sum(0) > 0).flatten()
+    r0, r1, c0, c1 = int(nzr[0]), int(nzr[-1]), int(nzc[0]), int(nzc[-1])
+    wraps = (sel[:, 0] + r0 < 0) | (sel[:, 0] + r1 > pn - 1) | (sel[:, 1] + c0 < 0) | (sel[:, 1] + c1 > pn - 1)
+    nw = int(wraps.sum())
+    assert 0 < nw < K, (nw, K)
+    ref = _oracle_chunked(o, mft.cpu(), pupil.cpu(), sel.cpu(), N, workers=K)
+    got = L.abbeIntensity(mft, pupil, sel, N, options={"split": 2, "poison": 1}).cpu()
+    plan = nat().last_plan()
+    assert plan["planned_from_record"] == 2 and plan["general"] == 1, plan
+    _check(got, ref, f"{pn}^2 shifted source, {nw} of {K} points wrap, split")
+    # the same call through the dry run: split, part 0 on the fast path (embedded for 3000^2), regions apart
+    a, b = sel[~wraps], sel[wraps]
+    ext = lambda t: [int(t[:, 0].min()), int(t[:, 0].max()), int(t[:, 1].min()), int(t[:, 1].max())]          # noqa: E731
+    words = [r0, r1, c0, c1] + ext(sel) + [K, 2**31 - 1, -2**31, 2**31 - 1, -2**31, 0]
+    dry = nat().plan_dry_run(pn, N, 1, words, [K - nw, nw] + ext(a) + ext(b), options={"split": 2})
+    assert dry.status == 0 and dry.split == 1 and dry.part[0].general == 0 and dry.part[1].general == 1
+    assert dry.part[0].run_size == L.embeddedSize(pn, N) and dry.part[1].run_size == pn
+    assert dry.part[0].T_region.end <= dry.list_a.offset and dry.part[1].T_region.end <= dry.list_a.offset
+    assert dry.part[1].batch == plan["batch"]                     # the part that ran last on the device is the wrapping one
+
+
 def test_environment_variables_remain_a_fallback_and_options_win(L, dev, monkeypatch):
     """Options passed per call beat the LITHO_ABBE_* variables; a field the caller leaves unset falls back to the variable,
     then to the default."""
@@ -530,12 +604,13 @@ def _fuzz_case(seed):
                 prefill=prefill, mode=mode)
 
 
-def test_seeded_fuzz_against_the_float64_oracle(L, dev):
+def _run_fuzz(L, dev, cases, what):
+    """Every case through the engine with its random options under NaN-poisoned scratch, against the float64 closed form; returns
+    the evaluation paths and kernel names reached."""
     o = O()
-    failures, worst, paths = [], 0.0, {}
-    for seed in range(FUZZ_CASES):
-        cs = _fuzz_case(seed)
-        pn = cs["pn"]
+    failures, worst, paths, kernels = [], 0.0, {}, set()
+    for cs in cases:
+        pn, seed = cs["pn"], cs["seed"]
         _, N = L.Mask.calculateEpsilonN(None, 4 / pn, cs["ps"], WL)
         ref = torch.stack([o.abbe_raw_f64(cs["mft"], cs["pupils"][k], cs["shifts"], N) for k in range(cs["planes"])])
         scale = float(ref.max()) if float(ref.max()) > 0 else 1.0
@@ -556,6 +631,7 @@ def test_seeded_fuzz_against_the_float64_oracle(L, dev):
                "wave" if plan["wave_ypass"] else "r16", plan["variant"])
         if cs["kind"] != "empty":
             paths[key] = paths.get(key, 0) + 1
+            kernels.update(nat().last_kernels())
         if not torch.isfinite(got).all():
             failures.append(f"{tag}: non-finite pixels (poisoned scratch read?) plan {plan}")
             continue
@@ -564,9 +640,61 @@ def test_seeded_fuzz_against_the_float64_oracle(L, dev):
         worst = max(worst, e)
         if e >= TOL_IMAGE_MAX or l2 >= TOL_IMAGE_L2:
             failures.append(f"{tag}: rel-to-max {e:.2e} rel-L2 {l2:.2e} plan {plan} kernels {nat().last_kernels()}")
-    print(f"fuzz: {FUZZ_CASES} cases, worst rel-to-max {worst:.2e}; evaluation paths hit: "
-          + ", ".join(f"{k}: {v}" for k, v in sorted(paths.items(), key=str)))
+    print(f"{what}: {len(cases)} cases, worst rel-to-max {worst:.2e}; evaluation paths hit: "
+          + ", ".join(f"{k}: {v}" for k, v in sorted(paths.items(), key=str)) + f"; kernels: {sorted(kernels)}")
     assert not failures, "\n".join(failures[:40])
+    return paths, kernels
+
+
+def test_seeded_fuzz_against_the_float64_oracle(L, dev):
+    paths, _ = _run_fuzz(L, dev, [_fuzz_case(seed) for seed in range(FUZZ_CASES)], "fuzz")
     # the fuzz is only worth its name if it reaches every family of the planner
     fams = {k[0] for k in paths}
     assert {"general", "coarse", "direct"} <= fams and any(k[1] == "wave" for k in paths) and any(k[1] == "r16" for k in paths), paths
+
+
+# ------------------------------------------------------------------ the same at the sizes of the BASELINE GPU configurations
+# (round-4 review, weak 1b: the small-size fuzz never reaches k_ypass_rect<10/11>, k_xpass_abbe<10..12>, k_ypass_coop*,
+# k_xpass_split<13>, k_ypass_pair -- the kernels that carry configs 2-5.)  Same pupil families, random options incl. the
+# 4096-only ones, pre-filled `out`, NaN-poisoned scratch, 1-2 source points x 1-3 planes, against the float64 closed form
+# (O(pn^3) per point: the host's zgemm does a 2048^2 point in a fraction of a second).
+def _fuzz_case_mid(seed, sizes):
+    gen = torch.Generator().manual_seed(7700000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=gen))          # noqa: E731
+    pick = lambda seq: seq[ri(0, len(seq) - 1)]                                      # noqa: E731
+    pn = pick(sizes)
+    kind = pick(["disk", "disk", "disk", "disk", "disk_rim", "disk_rim", "disk_junk", "disk_junk", "box", "single"])
+    planes = pick([1, 1, 1, 2, 3]) if pn < 4096 else pick([1, 1, 2])
+    S = pick([1, 2, 2]) if pn < 4096 else 1 if planes > 1 else pick([1, 2])
+    c, h = pn // 2, pn // 4
+    mode = pick(["narrow", "narrow", "narrow", "wide", "wide", "wrap"])
+    lim = {"narrow": max(1, int(0.2 * pn)), "wide": c - h, "wrap": c}[mode]
+    sh = torch.randint(-lim, lim + (0 if mode == "wrap" else 1), (S, 2), generator=gen, dtype=torch.int32)
+    opts = {"poison": 1, "coarse": pick([0, 2, 2, 2, 1])}
+    for name, values in (("batch", [0, 0, 1, 2, 3]), ("groups", [0, 0, 0, 1, 2, 4]), ("xchunk", [0, 0, 1, 2]),
+                         ("tile", [0, 0, 0, 4, 8] + ([16] if pn == 4096 else [])), ("plane_chunk", [0, 1, 2, 4]), ("gcombine", [1, 1, 0]),
+                         ("rect", [1, 1, 1, 0]), ("w64", [1, 1, 1, 1, 0]), ("xrect", [1, 1, 0, 2]), ("force_generic", [0, 0, 0, 0, 1]),
+                         ("force_general", [0, 0, 0, 0, 0, 1]), ("split", [1, 2, 2, 0]), ("xsplit", [1, 1, 0]), ("w64_8192", [1, 1, 0]),
+                         ("coopdma", [1, 1, 0]), ("rowpairs", [0, 0, 1])):
+        opts[name] = pick(values)
+    pupils = torch.stack([_fuzz_pupil(gen, kind, pn) for _ in range(planes)])
+    mft = torch.complex(torch.randn(pn, pn, generator=gen), torch.randn(pn, pn, generator=gen))
+    prefill = torch.rand(planes, pn, pn, generator=gen) if ri(0, 1) else torch.zeros(planes, pn, pn)
+    return dict(seed=seed, pn=pn, ps=25, kind=kind, planes=planes, shifts=sh, opts=opts, pupils=pupils, mft=mft,
+                prefill=prefill, mode=mode)
+
+
+def test_seeded_fuzz_mid_sizes_against_the_float64_oracle(L, dev):
+    paths, kernels = _run_fuzz(L, dev, [_fuzz_case_mid(seed, [1024, 1024, 2048]) for seed in range(48)], "fuzz 1024/2048")
+    fams = {k[0] for k in paths}
+    assert {"coarse", "direct"} <= fams and any(k[1] == "wave" for k in paths), paths
+    # the kernels of BASELINE configs 2, 3 and 5 (coarse grid) and their direct-path counterparts must have been reached
+    for must in ("k_ypass_rect<10, 8, true", "k_ypass_rect<11, 8, true", "k_xpass_abbe<10, 0, true", "k_xpass_abbe<11, 0, true"):
+        assert any(k.startswith(must) for k in kernels), (must, sorted(kernels))
+
+
+def test_seeded_fuzz_4096_against_the_float64_oracle(L, dev):
+    paths, kernels = _run_fuzz(L, dev, [_fuzz_case_mid(1000 + seed, [4096]) for seed in range(10)], "fuzz 4096")
+    assert any(k[0] == "coarse" for k in paths), paths
+    # config 4's kernels: the coarse grid's cooperative y-pass (either loader) and the 4096-point x-pass
+    assert any(k.startswith("k_ypass_coop") for k in kernels) and any(k.startswith("k_xpass_abbe<12, 0, true") for k in kernels), sorted(kernels)

@@ -1,0 +1,288 @@
+"""Host-only verification of the launch planner (round-4 review, item 4).
+
+The reference's source-point loop is six lines with nothing to plan (imageformation.py:62-67); the engine that replaced it
+plans batches, kernel families, embedded evaluation of odd mask sizes and the split of partly wrapping source lists, and places
+every intermediate at a hand-computed offset of ONE caller-provided workspace.  None of that needs a device: the decisions live
+in csrc/abbe_plan.hpp (no HIP dependency), litho_abbe_plan_dry_run exports them, and this file sweeps every admissible problem
+size on the CPU and asserts, for every plan:
+  * every region it uses lies inside litho_abbe_workspace_bytes(pn, N);
+  * regions that are live at the same time are pairwise disjoint;
+  * what a launch pair writes fits the region it writes into (T: batch x planes x item; slabs; coarse image);
+  * batch >= 1, groups >= 1, and an untruncated T region holds at least 1.5 general-mode items.
+No compute call, no GPU."""
+import ctypes
+import itertools
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+INT_MAX, INT_MIN = 2**31 - 1, -2**31
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from lithographysimulator_amd import _native
+    _native.lib()
+    return _native
+
+
+def admissible_N(pn):
+    return [N for N in (16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384) if N >= pn]
+
+
+def general_item_bytes(pn):
+    return ((pn + 3) // 4) * pn * 4 * 8
+
+
+def disk_words(pn, S, dy=(0, 0), dx=(0, 0), box=None, edges=True):
+    """Plan words of the reference's r <= 1 pupil (support |k| <= pn/4) -- or of `box` = (r0, r1, c0, c1) -- with the
+    shift extents given."""
+    c, h = pn // 2, pn // 4
+    r0, r1, c0, c1 = box if box else (c - h, c + h, c - h, c + h)
+    w = [r0, r1, c0, c1, dy[0], dy[1], dx[0], dx[1], S]
+    if edges and not box:
+        w += [c, c, c, c, 0]                     # the disk touches each edge of its box in one sample
+    else:
+        w += [INT_MAX, INT_MIN, INT_MAX, INT_MIN, 0]
+    return w
+
+
+def live_regions(res, part):
+    """(name, offset, end) of everything that is live while `part` runs its source-point loop."""
+    out = []
+    for name in ("plan", "twtab", "twtab2", "slab_used", "ic_used", "chat_used", "gam_used", "T_used", "embed_M", "embed_P", "embed_O"):
+        r = getattr(part, name)
+        if r.bytes:
+            out.append((name, r.offset, r.end))
+    if res.split:
+        out.append(("list_a", res.list_a.offset, res.list_a.end))
+        out.append(("list_b", res.list_b.offset, res.list_b.end))
+    return out
+
+
+def check_result(res, pn, N, planes, tag, expect_ok=True):
+    assert res.status == 0 or not expect_ok, f"{tag}: status {res.status}"
+    if res.status:
+        return 0
+    total = res.workspace_bytes
+    n = 0
+    for part in res.part:
+        if not part.present:
+            continue
+        n += 1
+        assert part.batch >= 1 and part.groups >= 1 and part.planes_in_flight >= 1 and part.xchunk >= 1, tag
+        assert 1 <= part.slabs <= part.groups, tag
+        assert part.planes_in_flight <= min(planes, 4) or not part.coarse, tag
+        # what is written fits where it is written
+        assert part.T_used.bytes == part.planes_in_flight * part.batch * part.t_item_bytes, tag
+        assert part.T_used.end <= part.T_region.end, f"{tag}: T use {part.T_used.bytes} > region {part.T_region.bytes}"
+        assert part.recon_T_used.end <= part.T_region.end, f"{tag}: reconstruction T {part.recon_T_used.bytes} > region {part.T_region.bytes}"
+        assert part.slab_used.end <= part.slab_region.end, f"{tag}: slabs {part.slab_used.bytes} > region {part.slab_region.bytes}"
+        # inside the workspace the query reports
+        for name in nat_regions:
+            r = getattr(part, name)
+            assert 0 <= r.offset and r.end <= total, f"{tag}: {name} [{r.offset}, {r.end}) outside the {total}-byte workspace"
+        regs = live_regions(res, part)
+        for (na, a0, a1), (nb, b0, b1) in itertools.combinations(regs, 2):
+            assert a1 <= b0 or b1 <= a0, f"{tag}: {na} [{a0}, {a1}) overlaps {nb} [{b0}, {b1})"
+        # an untruncated T region holds 1.5 general-mode items of the grid the part runs at
+        if not res.split:
+            assert part.T_region.bytes >= 1.5 * general_item_bytes(part.run_size) - 1, tag
+    if res.split:
+        for r in (res.list_a, res.list_b):
+            assert 0 <= r.offset and r.end <= total, tag
+        assert res.split_counts.end <= min(p.T_region.end for p in res.part if p.present and p.run_size == pn) if any(
+            p.present and p.run_size == pn for p in res.part) else True, tag
+    return n
+
+
+nat_regions = ("plan", "twtab", "twtab2", "slab_region", "slab_used", "ic_used", "chat_used", "gam_used", "T_region", "T_used", "recon_T_used",
+               "embed_M", "embed_P", "embed_O")
+
+
+def test_every_even_size_every_fft_size_every_plane_count(nat):
+    """Every even pn in [2, 16384] x every admissible N x planes in {1, 2, 5, 32}: the reference's disk pupil with a
+    non-wrapping annular source (the plain call), S from 1 to every pixel lit."""
+    checked = 0
+    for pn in range(2, 16385, 2):
+        # all sizes up to 600, then a stride that still hits every residue class the planner distinguishes, + the special ones
+        if pn > 600 and pn % 98 and pn not in (1000, 1024, 1500, 2000, 2048, 3000, 4094, 4096, 6000, 8190, 8192, 12000, 16382, 16384):
+            continue
+        for N in admissible_N(pn):
+            q = pn // 8                      # sigma_out 0.5-ish: shifts well inside the no-wrap range
+            for planes in (1, 2, 5, 32):
+                for S in (1, 300, pn * pn):
+                    res = nat.plan_dry_run(pn, N, planes, disk_words(pn, S, (-q, q), (-q, q)))
+                    checked += check_result(res, pn, N, planes, f"pn {pn} N {N} planes {planes} S {S}")
+                    assert res.nowrap == 1 and res.split == 0
+    assert checked > 20000, checked
+
+
+@pytest.mark.parametrize("coarse", [0, 1, 2])
+def test_baseline_configurations_plan_as_documented(nat, coarse):
+    """The five BASELINE configurations: the plan the dry run reports is the one DESIGN.md documents (and the GPU tests
+    assert through litho_abbe_last_plan)."""
+    for pn, S, planes, batch, tile, xkind in ((256, 3233, 1, None, 8, 1), (1024, 98832, 1, 48, 8, 1), (2048, 198108, 1, 12, 8, 1),
+                                              (4096, 197702, 1, 60, 16, 1), (2048, 198108, 32, 12, 8, 1)):
+        q = int(0.8 * pn / 4)
+        res = nat.plan_dry_run(pn, 2 * pn, planes, disk_words(pn, S, (-q, q), (-q, q)), options={"coarse": coarse})
+        check_result(res, pn, 2 * pn, planes, f"config pn {pn}")
+        p = res.part[0]
+        assert p.present and not res.part[1].present and p.natural_box == 1 and p.general == 0 and p.variant == 1
+        assert p.coarse == (1 if coarse else 0)
+        if coarse:
+            assert p.wave_y == 1 and p.tile == tile and p.xkind == xkind
+            if batch:
+                assert p.batch == batch, (pn, p.batch)
+            if pn == 4096:
+                assert p.xchunk == 15 and p.T_used.bytes == 60 * 2049 * 4096 * 8
+
+
+def test_embedded_sizes(nat):
+    """Mask sizes other than N and N / 2 run embedded: padded layout + scratch behind it, all
+    inside the reported workspace; a wrapping list refuses the embedding and runs the general path at the caller's size; a
+    workspace sized for the own grid only runs un-embedded."""
+    for pn, ps_N, pe in ((200, 512, 256), (1000, 2048, 1024), (1500, 4096, 2048), (3000, 8192, 4096), (6000, 16384, 8192),
+                         (300, 1024, 512), (2048, 8192, 4096), (5000, 8192, 8192), (12000, 16384, 16384)):
+        for planes in (1, 3, 5, 32):
+            q = pn // 10
+            res = nat.plan_dry_run(pn, ps_N, planes, disk_words(pn, 5000, (-q, q), (-q, q)))
+            check_result(res, pn, ps_N, planes, f"embedded pn {pn}")
+            p = res.part[0]
+            assert res.run_size == pe and p.run_size == pe and p.embed_M.bytes == pe * pe * 8, (pn, res.run_size)
+            assert p.embed_O.end <= res.workspace_bytes
+            # a wrapping list: general path at the caller's size, nothing embedded
+            big = pn // 2
+            res = nat.plan_dry_run(pn, ps_N, planes, disk_words(pn, 100, (-big, big), (-big, big)), options={"split": 0})
+            check_result(res, pn, ps_N, planes, f"embedded-refused pn {pn}")
+            assert res.nowrap == 0 and res.part[0].run_size == pn and res.part[0].general == 1 and res.part[0].embed_M.bytes == 0
+            # an older, smaller workspace (the own-size regions only)
+            own = ctypes.c_size_t(0)
+            small = nat.plan_dry_run(pn, ps_N, planes, disk_words(pn, 5000, (-q, q), (-q, q)), options={"embed": 0})
+            assert small.part[0].run_size == pn and small.part[0].embed_M.bytes == 0
+            del own
+
+
+def test_split_source_lists(nat):
+    """A partly wrapping (shifted) source list is split: two lists at the end of the T region of the grid the non-wrapping part
+    runs at, both carves' T regions cut short of them -- at the sizes the GPU tests cannot afford (2048^2, 4096^2, embedded
+    3000^2 in 4096, 6000^2 in 8192), with S up to every pixel lit (the longest lists a caller can pass)."""
+    for pn, N in ((256, 512), (1000, 2048), (1024, 2048), (2048, 4096), (3000, 8192), (4096, 8192), (6000, 16384), (8192, 16384), (16384, 16384)):
+        c, h = pn // 2, pn // 4
+        for planes in (1, 2, 5, 32):
+            for S in (256, 100000, pn * pn):
+                S = min(S, pn * pn)
+                n_a = S * 2 // 3
+                wrap = c - h + 40                                   # shifts beyond c - h wrap the disk's box
+                words = disk_words(pn, S, (-wrap, c - h - 1), (-10, wrap))
+                sw = [n_a, S - n_a, -(c - h), c - h - 1, -10, c - h - 1, -wrap, c - h - 1, -10, wrap]
+                res = nat.plan_dry_run(pn, N, planes, words, sw)
+                tag = f"split pn {pn} N {N} planes {planes} S {S}"
+                check_result(res, pn, N, planes, tag)
+                if not res.split:
+                    # refused: the two lists would not leave 64 MiB of T (16384^2 with every pixel lit: 2 x 2 GiB of lists against
+                    # a 4 GiB T region) -- then the WHOLE list runs the general path on the untruncated workspace
+                    assert 2 * 8 * S + (64 << 20) >= res.part[0].T_region.bytes and res.part[0].general == 1 and not res.part[1].present, tag
+                    continue
+                assert res.nowrap == 0, tag
+                a, b = res.part
+                assert a.present and b.present and a.general == 0 and b.general == 1 and b.run_size == pn, tag
+                assert a.source_points == n_a and b.source_points == S - n_a
+                # the lists sit behind BOTH T regions, and end where the T region of the non-wrapping part's grid ends
+                assert a.T_region.end <= res.list_a.offset and b.T_region.end <= res.list_a.offset, tag
+                assert res.list_a.bytes >= 8 * S and res.list_b.offset == res.list_a.end, tag
+                # the truncated T regions still hold what the plans put there (asserted in check_result) and >= 64 MiB
+                assert a.T_region.bytes > (64 << 20) and b.T_region.bytes > (64 << 20), tag
+        # the unsplit alternative of the same list: everything on the general path
+        res = nat.plan_dry_run(pn, N, 1, words, None, options={"split": 0})
+        check_result(res, pn, N, 1, f"unsplit pn {pn}")
+        assert res.split == 0 and res.part[0].general == 1
+
+
+def test_random_options_and_boxes(nat):
+    """Seeded sweep over random support boxes (natural, one-sided, full grid), shift extents (narrow / wrapping), plane
+    counts and EVERY planner option: whatever the plan, its regions stay inside the workspace and apart."""
+    import random
+    rng = random.Random(20261003)
+    sizes = [64, 96, 128, 200, 256, 300, 512, 768, 1000, 1024, 1500, 2048, 3000, 4096, 6000, 8192, 16384]
+    names = dict(batch=[0, 0, 1, 2, 3, 5, 8, 60, 1000], groups=[0, 0, 1, 2, 3, 4, 64], xchunk=[0, 0, 1, 2, 3, 15], tile=[0, 0, 4, 8, 16],
+                 plane_chunk=[0, 1, 2, 4], gcombine=[1, 0], rect=[1, 0], w64=[1, 0], xrect=[1, 0, 2], force_generic=[0, 0, 1],
+                 force_general=[0, 0, 1], split=[1, 2, 0], embed=[1, 0], coarse=[0, 1, 2], w64_8192=[1, 0], xsplit=[1, 0], w64x=[0, 1],
+                 rowpairs=[0, 1], coopdma=[1, 0])
+    done = 0
+    for _ in range(6000):
+        pn = rng.choice(sizes)
+        N = rng.choice(admissible_N(pn)[:3])
+        c, h = pn // 2, pn // 4
+        planes = rng.choice([1, 1, 2, 3, 5, 32])
+        kind = rng.choice(["disk", "disk", "onesided", "full", "small"])
+        if kind == "disk":
+            box = None
+        elif kind == "onesided":
+            box = (c - h, min(pn - 1, c + h + rng.randint(1, h)), c - h, c + h)
+        elif kind == "full":
+            box = (0, pn - 1, 0, pn - 1)
+        else:
+            r0, c0 = rng.randint(0, pn - 2), rng.randint(0, pn - 2)
+            box = (r0, rng.randint(r0, pn - 1), c0, rng.randint(c0, pn - 1))
+        lim = rng.choice([max(1, pn // 10), c - h, c])
+        S = rng.choice([1, 7, 255, 256, 4000, pn * pn])
+        words = disk_words(pn, S, (-rng.randint(0, lim), rng.randint(0, lim)), (-rng.randint(0, lim), rng.randint(0, lim)), box)
+        n_a = rng.randint(0, S)
+        sw = [n_a, S - n_a] + words[4:8] + words[4:8]
+        opts = {k: rng.choice(v) for k, v in names.items()}
+        res = nat.plan_dry_run(pn, N, planes, words, sw, options=opts)
+        done += check_result(res, pn, N, planes, f"random pn {pn} N {N} planes {planes} {kind} S {S} {opts}", expect_ok=False)
+    assert done > 5000, done
+
+
+def test_planner_header_compiles_without_hip(tmp_path):
+    """csrc/abbe_plan.hpp + plan_dry_run.cpp are plain C++: they build with g++ alone, no HIP header on the include path,
+    into a library that exports the entry point."""
+    out = tmp_path / "libplan_only.so"
+    src = os.path.join(ROOT, "lithographysimulator_amd", "csrc", "plan_dry_run.cpp")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-shared", "-fPIC", "-nostdinc++" if False else "-fno-exceptions",
+                           src, "-o", str(out)])
+    lib = ctypes.CDLL(str(out))
+    assert hasattr(lib, "litho_abbe_plan_dry_run")
+    deps = subprocess.run(["ldd", str(out)], capture_output=True, text=True).stdout
+    assert "amdhip" not in deps and "hsa" not in deps, deps
+
+
+def test_plan_record_packing_round_trip():
+    """The 16-word caller-held record: pack / unpack of the plan words and of the split's ten words (a tiny C++ driver around
+    csrc/abbe_plan.hpp, compiled here)."""
+    import tempfile
+    code = r'''
+#include <cstdio>
+#include "%s"
+using namespace litho;
+int main() {
+    int bad = 0;
+    const int cases[][14] = {{512, 1536, 512, 1536, -409, 409, -409, 409, 198108, 1024, 1024, 1024, 1024, 0},
+                             {0, 16383, 0, 16383, -8192, 8191, -8192, 8191, 268435456, INT_MAX, INT_MIN, INT_MAX, INT_MIN, 1},
+                             {INT_MAX, INT_MIN, INT_MAX, INT_MIN, INT_MAX, INT_MIN, INT_MAX, INT_MIN, 0, INT_MAX, INT_MIN, 5, 900, 0}};
+    const int sws[][10] = {{100000, 98108, -409, 200, -409, 409, 201, 409, -300, 409}, {1, 268435455, 0, 0, 0, 0, -8192, 8191, -8192, 8191},
+                           {0, 0, INT_MAX, INT_MIN, INT_MAX, INT_MIN, INT_MAX, INT_MIN, INT_MAX, INT_MIN}};
+    for (int c = 0; c < 3; ++c) for (int split = 0; split < 2; ++split) for (int pe : {2, 256, 4096, 16384}) {
+        int32_t w[16]; int pl[14], sw[10];
+        record_store(w, cases[c], pe, split ? sws[c] : nullptr);
+        if (!record_is_ours(w) || record_count(w) != cases[c][8] || record_run_size(w) != pe) ++bad;
+        const bool s = record_load(w, pl, sw);
+        if (s != (split != 0)) ++bad;
+        for (int i = 0; i < 14; ++i) if (pl[i] != (i == 13 ? (cases[c][13] ? 1 : 0) : cases[c][i])) ++bad;
+        if (split) { if (sw[0] != sws[c][0] || sw[1] != cases[c][8] - sws[c][0]) ++bad; for (int i = 2; i < 10; ++i) if (sw[i] != sws[c][i]) ++bad; }
+    }
+    int32_t z[16] = {0}; if (record_is_ours(z)) ++bad;
+    printf("%%d\n", bad);
+    return bad;
+}''' % os.path.join(ROOT, "lithographysimulator_amd", "csrc", "abbe_plan.hpp")
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.cpp"), "w").write(code)
+        subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(d, "t.cpp"), "-o", os.path.join(d, "t")])
+        r = subprocess.run([os.path.join(d, "t")], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.strip() == "0", (r.returncode, r.stdout, r.stderr)

@@ -61,14 +61,7 @@ namespace litho {
 // register.  One DMA instruction moves the 64 lanes' 16-byte pieces (one live slot of the column pair) to 1 KB of LDS:
 // (2 JL + 1) NL/2 KB per line group, which must fit the wave's LDS region (PF_BYTES).
 // ----------------------------------------------------------------------------------
-// one LDS-DMA instruction: lane i's 16 bytes at byte offset `voff` of the buffer -> LDS bytes [16 i, 16 i + 16) of `dst`
-// (dst must be wave-uniform: it travels in M0)
-__device__ __forceinline__ void dma_b128_to_lds(__amdgpu_buffer_rsrc_t r, unsigned char* dst, unsigned voff)
-{
-#if defined(__HIP_DEVICE_COMPILE__)       // (the host pass has no LDS address space to cast to)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, voff, 0, 0, 0);
-#endif
-}
+// (dma_b128_to_lds: since round 5 in the product header, csrc/wave_kernels.hpp -- k_ypass_coop_dma uses it)
 
 template <int LOG2N, bool FULL>
 struct RectPrefetch {

@@ -577,6 +577,60 @@ def test_config3_long_consecutive_run_vs_golden(golden, L, dev, path):
         assert abs(float(img.double().sum()) / float(g[f"cfg3run_{tag}_sum"]) - 1) < 2e-6
 
 
+@pytest.mark.parametrize("path", ["coarse", "coarse-coopreg", "direct"])
+def test_config4_fold_run_vs_golden(golden, L, dev, path):
+    """BASELINE config 4 -- the 8-GPU headline size -- at its DEFAULT launch geometry on the reference's dense data (golden g17,
+    round-4 review missing #3): 4,000 consecutive source points [400000, 404000) of the 4096^2 annular list, accumulated by
+    the reference's own abbeImage (77 minutes of CPU): 66 of the planner's 60-point batches + a ragged 40, i.e. MORE than one
+    64-batch slab fold (3,840 points), so the two-level summation at this size is compared with the reference's sequential
+    fp32 loop -- until now the fold at 4096^2 was checked only against the three-order closed form and GPU-vs-GPU.  Raw and
+    the 4094^2 post-processed image (quirk Q5): centre crop, a stride-32 grid over the whole image, eight whole rows, every
+    row / column sum, maximum, total; plan and kernel names asserted; default coarse grid (k_ypass_coop_dma), its
+    register-loading predecessor (k_ypass_coop) and the direct path (k_xpass_split + k_ypass_pair)."""
+    from lithographysimulator_amd import _native as nat
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    g = golden("g17_config4_fold_run.npz")
+    pn = 4096
+    lo, hi, S = (int(v) for v in g["cfg4run_range"])
+    assert hi - lo == 4000
+    mask = L.Mask(bernoulli_mask(pn), PS, dev)
+    mft = mask.fraunhofer(WL, True)
+    eps, N = mask.calculateEpsilonN(mask.deltaK, PS, WL)
+    sh = L.sourceShifts(L.LightSource(0.4, 0.8, pn, NA, device=dev).generateAnnular(), pn)
+    assert sh.shape[0] == S == 1581616
+    sel = sh[lo:hi]
+    assert np.array_equal(sel[[0, -1]].cpu().numpy(), g["cfg4run_first_last_shift"])
+    pf = L.Pupil(pn, WL, NA, f16([0, 0, 0, 0, 100]), dev).generatePupilFunction()
+    opts = {"coarse": 0 if path == "direct" else 1}               # 1 = the default rule
+    if "coopreg" in path: opts["coopdma"] = 0
+    raw = L.abbeIntensity(mft, pf, sel, N, options=opts)
+    plan = nat.last_plan()
+    kx, ky = nat.last_kernels()
+    assert plan["coarse_grid"] == (0 if path == "direct" else 1), plan
+    if path == "direct":
+        assert (kx, ky) == ("k_xpass_split<13>", "k_ypass_pair<13, 8>"), (kx, ky)
+        assert plan["launches"] > 64, plan                        # the direct path's batch is shorter: more folds still
+    else:
+        assert (plan["batch"], plan["launches"], plan["xchunk"]) == (60, 67, 15), plan
+        assert (kx, ky) == ("k_xpass_abbe<12, 0, true, 1, 1>", "k_ypass_coop<12, 4>" if "coopreg" in path else "k_ypass_coop_dma<12, 4>"), (kx, ky)
+    final = L.postProcess(raw, eps).cpu()
+    raw = raw.cpu()
+    assert tuple(final.shape) == (4094, 4094) == tuple(g["cfg4run_final_shape"])
+    for tag, img in (("raw", raw), ("final", final)):
+        mx = float(g[f"cfg4run_{tag}_max"])
+        n = img.shape[0]
+        e_crop = rel_max(crop_center(img), g[f"cfg4run_{tag}_crop"])
+        e_grid = float(np.abs(img[::32, ::32].numpy().astype(np.float64) - g[f"cfg4run_{tag}_stride32"]).max() / mx)
+        rows = img[[0, 1, 1023, 2047, 2048, 3071, n - 2, n - 1], :].numpy().astype(np.float64)
+        e_rows = float(np.abs(rows - g[f"cfg4run_{tag}_rows"]).max() / mx)
+        print(f"4096^2 run of {hi - lo} points, {path} path, {tag}: crop {e_crop:.2e}, stride-32 grid {e_grid:.2e}, 8 rows {e_rows:.2e} (rel to max)")
+        assert e_crop < TOL_IMAGE_MAX and e_grid < TOL_IMAGE_MAX and e_rows < TOL_IMAGE_MAX
+        assert np.allclose(img.double().sum(1).numpy(), g[f"cfg4run_{tag}_rowsum"], rtol=2e-5, atol=2e-6 * float(g[f"cfg4run_{tag}_rowsum"].max()))
+        assert np.allclose(img.double().sum(0).numpy(), g[f"cfg4run_{tag}_colsum"], rtol=2e-5, atol=2e-6 * float(g[f"cfg4run_{tag}_colsum"].max()))
+        assert abs(float(img.max()) / mx - 1) < 2e-5
+        assert abs(float(img.double().sum()) / float(g[f"cfg4run_{tag}_sum"]) - 1) < 2e-6
+
+
 @pytest.mark.parametrize("path", ["coarse", "direct", "coarse-tile8", "coarse-tile8-rowpairs", "coarse-default-batch", "direct-default-batch",
                                   "coarse-coopreg", "coarse-coopreg-default-batch"])
 def test_consecutive_shard_4096_vs_golden(golden, L, dev, monkeypatch, path):

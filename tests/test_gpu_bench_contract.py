@@ -36,6 +36,10 @@ def test_bench_json_contract():
     for key in ("fabric_GBs", "fabric_frac", "effective_40B_GBs", "effective_40B_over_peak", "copy_ceiling_GBs", "hbm_peak_GBs"):
         assert key in rl, key
     assert rl["hbm_peak_GBs"] == 8000.0 and "hbm" not in rl
+    # the HBM-honest block says whether fabric bytes ARE HBM bytes for this workload (256^2: no, T stays in the Infinity Cache)
+    assert rl["hbm_honest"]["hbm_streaming"] is False and "hbm_frac" not in rl["hbm_honest"]
+    assert r["target_abs"]["per_gpu"] == 1.2e11 and abs(r["target_abs"]["value_over_target"] - r["value"] / 1.2e11) < 1e-6 * r["value"] / 1.2e11
+    assert r["prediction"]["predicted_speedup"] == 1.0
     if rl["traffic"] is not None:
         assert rl["fabric_frac"] <= 1
     # kernel names come from the library (litho_abbe_last_kernels), spelt as rocprofv3 prints them
@@ -72,6 +76,20 @@ def test_bench_launches_its_own_ranks(world):
     assert len(rk["step_ms"]) == world and len(rk["compute_ms"]) == world and len(rk["allreduce_wait_ms"]) == world
     assert rk["source_points"] == shards and sum(shards) == 3233 and rk["allreduce_bytes"] == 256 * 256 * 4
     assert rk["step_ms_max"] >= rk["step_ms_min"] > 0 and min(rk["compute_ms"]) > 0
+    # who ran: world size, backend, one identity per rank (here all ranks share cuda:0 -> one distinct device), and the
+    # expectation the first real N-GPU record is to be judged against, stated in the record itself
+    assert rk["world"] == world and rk["backend"] == "gloo" and rk["rccl_version"] is None
+    assert len(rk["devices"]) == world and rk["distinct_devices"] == 1 and "pci" in rk["devices"][0]
+    pr = r["prediction"]
+    assert pr["predicted_step_ms"] > 0 and 1.0 < pr["predicted_speedup"] <= world and pr["predicted_allreduce_ms"] > 0
+
+
+def test_bench_refuses_a_world_size_other_than_gpus():
+    """--gpus N under a launcher that started another number of ranks would report the wrong n_gpus: refused before any GPU work."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cfg1", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr
 
 
 def test_bench_rank_failure_does_not_hang():

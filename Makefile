@@ -12,6 +12,11 @@ FFTFLAGS := -fno-signed-zeros -fno-slp-vectorize
 # strategy.  Same-box A/B (us per source point, default vs max-ilp): k_ypass_wave<12> 9.21 -> 9.03, but its full-output
 # variant (the coarse-grid path at 4096^2) spills 73 registers under max-ilp against 3 -- so: default everywhere.
 WAVEFLAGS_12 ?=
+# instw_11 (k_ypass_rect<11, ...>: configs 3 and 5): the transposes' 16 LDS read bases re-derived per line instead of living in
+# registers across the loop (LITHO_TRANSPOSE_OPAQUE, wave_fft.hpp) -- bit-identical, y-pass 4.60 / 4.64 -> 4.54 / 4.55 us per
+# source point in two alternating A/B pairs on one box (round 5); 1024^2 is indifferent (1.00 / 1.01 vs 1.01 / 0.99), and at
+# instw_12 the same switch makes k_ypass_wave<12, 4, true> spill 54 registers: 11 only.
+WAVEFLAGS_11 ?= -DLITHO_TRANSPOSE_OPAQUE
 # and the N = 8192 split x-pass: 28.5 -> 27.0 us per source point at 4096^2 (the N = 4096 x-pass prefers the default)
 INSTFLAGS_13 ?= -mllvm -amdgpu-sched-strategy=max-ilp
 INST := $(patsubst $(CSRC)/%.hip,build/%.o,$(wildcard $(CSRC)/inst_*.hip))

@@ -215,6 +215,9 @@ struct WaveSq {
     // slot brev(m) of lane l  ->  slot l of lane m (natural slot order on return)
     __device__ static __forceinline__ void transpose(float2 (&x)[S], float* lds, int lane)
     {
+#ifdef LITHO_TRANSPOSE_OPAQUE              // build-time experiment: the 16 read bases re-derived per call instead of hoisted out of the caller's loop
+        asm volatile("" : "+v"(lane));
+#endif
         const int l = lane & (S - 1), line = lane >> LS;
         // S x S transpose, real parts then imaginary parts, through this line's private matrix:
         // element (row = writer lane, col = m); reader lane m takes column m.
@@ -262,6 +265,9 @@ struct WaveSq {
             if constexpr (b != 0) x[sl] = cmul(x[sl], tw.row[b]);
             if constexpr (a != 0) x[sl] = cmul(x[sl], tw.row[8 + a]);
         });
+#ifdef LITHO_TRANSPOSE_OPAQUE
+        asm volatile("" : "+v"(lane));
+#endif
         float* const wr = lds + lane * (S + 1);
         float* const rd = lds + lane;
         static_for<0, S>([&](auto c_) { constexpr int c = decltype(c_)::value; wr[c] = x[slot_of(c)].x; });

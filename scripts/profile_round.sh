@@ -16,7 +16,7 @@ python3 bench.py --workload cfg4 --shard 0/8 --steps 1 --warmup 1 --no-cpu-basel
 python3 bench.py --workload cfg3 --shard 0/8 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_cfg3_shard0of8.json 2>/dev/null
 python3 bench.py --workload cfg5 --shard 0/8 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_cfg5_shard0of8.json 2>/dev/null
 # SKIP_PMC=1: bench lines and kernel stats only (e.g. after profiles/traffic.json has been refreshed from the PMC passes)
-[ -n "$SKIP_PMC" ] || bash scripts/pmc_traffic.sh $R cfg3 504 cfg2 2016 cfg4 64 cfg5 120 cfg1 3233
+[ -n "$SKIP_PMC" ] || bash scripts/pmc_traffic.sh $R cfg3 504 cfg2 3312 cfg4 64 cfg5 120 cfg1 3233   # (cfg2: 69 x its 48-point batch; a list of at most 64 x the 51-item cap -- a shorter list is re-batched evenly, 51 x 3-point chunks at 2016 points: another geometry than the full run's, caught by bench.py's geometry key in round 5)
 # keep the summaries small: the raw per-dispatch CSVs stay in gpurun_out
 find $O -name "*_agent_info.csv" -delete
 find $O/stats -name "*_kernel_trace.csv" -delete        # 80k rows per image: the stats csv is the summary that gets committed

@@ -505,6 +505,60 @@ def test_shifted_source_split_at_the_large_sizes(L, dev, pn, K):
     assert dry.part[1].batch == plan["batch"]                     # the part that ran last on the device is the wrapping one
 
 
+def _plan_words_of(pupils, shifts, pe):
+    """The 14 plan words the engine reads back (k_pupil_box + k_shift_extents), computed on the host from the tensors: support box
+    of the non-zero pupil samples over all planes, shift extents, count, supports on the natural-box edges of the grid the engine
+    will run at (pe), corner flag."""
+    INT_MAX, INT_MIN = 2**31 - 1, -2**31
+    pn = pupils.shape[-1]
+    nz = (pupils.reshape(-1, pn, pn) != 0).any(0)
+    rows, cols = torch.nonzero(nz.any(1)).flatten(), torch.nonzero(nz.any(0)).flatten()
+    if rows.numel() == 0:
+        return None
+    w = [int(rows[0]), int(rows[-1]), int(cols[0]), int(cols[-1]), int(shifts[:, 0].min()), int(shifts[:, 0].max()),
+         int(shifts[:, 1].min()), int(shifts[:, 1].max()), int(shifts.shape[0])]
+    lo, hi = pn // 2 - pe // 4, pn // 2 + pe // 4
+    ecols = [c for c in (lo, hi) if 0 <= c < pn]
+    er = torch.nonzero(nz[:, ecols].any(1)).flatten() if ecols else torch.zeros(0)
+    ec = torch.nonzero(nz[ecols, :].any(0)).flatten() if ecols else torch.zeros(0)
+    w += [int(er[0]), int(er[-1])] if er.numel() else [INT_MAX, INT_MIN]
+    w += [int(ec[0]), int(ec[-1])] if ec.numel() else [INT_MAX, INT_MIN]
+    w.append(int(any(bool(nz[r, c]) for r in ecols for c in ecols)))
+    return w
+
+
+def test_dry_run_predicts_the_plan_the_device_call_reports(L, dev):
+    """litho_abbe_plan_dry_run and the real call share their planning code (csrc/abbe_plan.hpp); this ties the CPU sweep of
+    tests/test_planner_cpu.py to the engine: for 120 cases of the seeded fuzz (random pupils, shifts, planes and options -- unsplit
+    lists) the dry run, fed with plan words computed on the HOST from the tensors, reports exactly the plan that
+    litho_abbe_last_plan returns after the device call: path, box, batch, groups, chunk, planes in flight, x-pass kind."""
+    checked = 0
+    for seed in range(120):
+        cs = _fuzz_case(seed)
+        if cs["kind"] == "empty":
+            continue
+        pn = cs["pn"]
+        _, N = L.Mask.calculateEpsilonN(None, 4 / pn, cs["ps"], WL)
+        opts = dict(cs["opts"], split=0, poison=0)
+        stacked = cs["planes"] > 1
+        pup = (cs["pupils"] if stacked else cs["pupils"][0]).to(dev)
+        L.abbeIntensity(cs["mft"].to(dev), pup, cs["shifts"].to(dev), N, options=opts)
+        plan = nat().last_plan()
+        pe = L.embeddedSize(pn, N) if opts.get("embed", 1) else pn
+        words = _plan_words_of(cs["pupils"], cs["shifts"], pe)
+        dry = nat().plan_dry_run(pn, N, cs["planes"], words, None, options=opts, cus=torch.cuda.get_device_properties(dev).multi_processor_count)
+        assert dry.status == 0 and dry.split == 0, seed
+        p = dry.part[0]
+        if p.run_size != pn and cs["planes"] > 4:
+            continue        # an embedded stack is padded four planes at a time: last_plan describes the LAST chunk (one plane here)
+        tag = f"seed {seed}: pn {pn} N {N} {cs['kind']} planes {cs['planes']} {cs['mode']} {opts} -> device {plan} / dry batch {p.batch} G {p.groups} xchunk {p.xchunk}"
+        assert p.present and (p.general, p.coarse, p.wave_y, p.natural_box) == (plan["general"], plan["coarse_grid"], plan["wave_ypass"], plan["natural_box"]), tag
+        assert (p.batch, p.groups, p.xchunk, p.planes_in_flight, p.variant, p.xkind) == (
+            plan["batch"], plan["groups_per_plane"], plan["xchunk"], plan["planes_in_flight"], plan["variant"], plan["fused_xpass"]), tag
+        checked += 1
+    assert checked >= 100
+
+
 def test_environment_variables_remain_a_fallback_and_options_win(L, dev, monkeypatch):
     """Options passed per call beat the LITHO_ABBE_* variables; a field the caller leaves unset falls back to the variable,
     then to the default."""

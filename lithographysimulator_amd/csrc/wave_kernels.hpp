@@ -396,7 +396,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ypass_coop_dma(
 
     // blocks b, b + 8, ... (same XCD, back to back) take the PARTS parts of one 16-column tile
     const int b = blockIdx.x;
+#if !defined(LITHO_COOP_MAP) || LITHO_COOP_MAP == 0
     const int tile = (b / (8 * CS::PARTS)) * 8 + (b & 7), part = (b >> 3) % CS::PARTS;
+#elif LITHO_COOP_MAP == 1
+    // experiment: the two workgroups that SHARE A CU (XCD-local workgroups j and j + 32, if the dispatcher fills the 32 CUs of an
+    // XCD round-robin, one slot at a time) take adjacent parts of one tile, so that their L1 serves each 128-byte line twice
+    const int xcd = b & 7, j = b >> 3, rnd = j >> 6, jj = j & 63, q = (jj & 31) + 32 * rnd;
+    const int tile = (q >> 1) * 8 + xcd, part = 2 * (q & 1) + (jj >> 5);
+#else
+    // experiment: the same for consecutive XCD-local workgroups (j, j + 1)
+    const int xcd = b & 7, j = b >> 3, k = j >> 1;
+    const int tile = (k >> 1) * 8 + xcd, part = 2 * (k & 1) + (j & 1);
+#endif
     const int qx = tile * TC + part * NW + wv;
     const int plane = blockIdx.y / G, grp = blockIdx.y - plane * G;
     Tbuf += (size_t)plane * nb * g.t_point;

@@ -353,9 +353,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ypass_coop(
 // ----------------------------------------------------------------------------------
 template <int NW>
 struct CoopDmaShape {
-    static_assert(NW == 4, "four waves share four columns (32 bytes) of a tile row");
+    static_assert(NW == 4 || NW == 8, "four waves share four columns (32 bytes) of a tile row -- or, as an experiment, eight share 64 bytes");
     static constexpr int S = 64, N = 4096, JLIVE = 16, NLIVE = 2 * JLIVE + 1;
-    static constexpr int UNITS = (NLIVE + 1) / 2;                                   // 1 KB units (32 rows x 32 bytes) per wave and line
+    static constexpr int QB = NW / 2;                                               // 16-byte pieces of a tile row the workgroup owns
+    static constexpr int RPU = 64 / QB;                                             // rows per 1 KB unit (32 x 32 bytes, or 16 x 64 bytes)
+    static constexpr int UNITS = (NLIVE + 1) / 2;                                   // 1 KB units per wave and line
     static constexpr int WAVE_BYTES = UNITS * 1024;                                 // 17 KB >= the 64 x 65 fp32 matrix
     static_assert(WAVE_BYTES >= WaveSq<6>::LDS_FLOATS * 4 && WAVE_BYTES % 256 == 0, "a region holds the transpose matrix; regions bank-aligned");
     static constexpr size_t LDS_BYTES = NW * (size_t)WAVE_BYTES + (size_t)WaveSq<6>::TW_LDS_FLOAT2 * sizeof(float2);
@@ -417,9 +419,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ypass_coop_dma(
     static_for<0, S>([&](auto i) { acc[i] = 0.f; });
 
     const unsigned tile_bytes = active ? (unsigned)g.rows * RB : 0u;
-    // Units (live slot, half of its 64 rows): wave wv takes the half h = wv & 1 of the slots i0 = wv >> 1, i0 + 2, ...
-    const int i0 = wv >> 1, h = wv & 1;                        // wave-uniform
-    const unsigned sb = (unsigned)(-g.ky0 * RB + part * PART_BYTES + i0 * RB * S + h * 32 * RB);
+    // Units (live slot, half -- NW = 8: quarter -- of its 64 rows): wave wv takes the rows RPU h .. of the slots i0, i0 + 2, ...
+    constexpr int QB = CS::QB, RPU = CS::RPU;
+    const int i0 = wv / QB, h = wv % QB;                       // wave-uniform
+    const unsigned sb = (unsigned)(-g.ky0 * RB + part * PART_BYTES + i0 * RB * S + h * RPU * RB);
     constexpr int NM = CS::UNITS;                              // 17 units for i0 = 0, 16 for i0 = 1
 
     // units [M0, M1) of line s
@@ -435,9 +438,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ypass_coop_dma(
         int ln = lane;
         asm volatile("" : "+v"(ln));
 #ifdef LITHO_COOP_DMA_NOSWZ
-        const int lrow = ln >> 1, le = ln & 1;
+        const int lrow = ln / QB, le = ln % QB;
 #else
-        const int lrow = ln >> 1, le = (ln ^ (ln >> 4)) & 1;
+        // (QB = 2: piece ^= bit 3 of the row; QB = 4: piece ^= bits 2-3 of the row -- granule QB row + piece then covers every
+        // 16-byte position of a 256-byte bank row equally often for a fixed column)
+        const int lrow = ln / QB, le = (ln ^ (lrow / (16 / QB))) % QB;
 #endif
 #if defined(LITHO_DIAG_COOP_DMA_MODE) && LITHO_DIAG_COOP_DMA_MODE == 1     // timing diagnostics (wrong results): one row per instruction,
         const unsigned vbx = (unsigned)le * 16u + sb + 0 * lrow;
@@ -460,14 +465,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ypass_coop_dma(
 
     // reader: lane = row of the slot (half hh = lane >> 5, row r = lane & 31 of its unit); column wv = 16-byte half e, float2 c
     // of the half.  Live slot li sits in the region of wave 2 (li & 1) + hh, unit li >> 1, granule 2 r + (e ^ bit 3 of r).
-    const int rr = lane & 31, hh = lane >> 5;
+    const int rr = lane % RPU, hh = lane / RPU;
 #ifdef LITHO_COOP_DMA_NOSWZ
-    const unsigned rd_lane = (unsigned)((2 * rr + (wv >> 1)) * 16 + (wv & 1) * 8);
+    const unsigned rd_lane = (unsigned)((QB * rr + (wv >> 1)) * 16 + (wv & 1) * 8);
 #else
-    const unsigned rd_lane = (unsigned)((2 * rr + ((wv >> 1) ^ ((rr >> 3) & 1))) * 16 + (wv & 1) * 8);
+    const unsigned rd_lane = (unsigned)((QB * rr + (((wv >> 1) ^ (rr / (16 / QB))) % QB)) * 16 + (wv & 1) * 8);
 #endif
     const unsigned char* const rd_even = smem_raw + hh * CS::WAVE_BYTES + rd_lane;
-    const unsigned char* const rd_odd = rd_even + 2 * CS::WAVE_BYTES;
+    const unsigned char* const rd_odd = rd_even + QB * CS::WAVE_BYTES;
     auto live_index = [](int j) constexpr { return j <= JLIVE ? j : j - (S - NLIVE); };
 
     if (grp < nb) prefetch(grp);
@@ -934,13 +939,17 @@ hipError_t launch_ypass_wave(const float2* T, float* slab, const float2* tw, con
 #endif
             constexpr int NW = LITHO_COOP_WAVES;
             if (g.coop_dma) {
+#ifndef LITHO_COOP_DMA_WAVES                     // build-time experiment: 8 = eight waves own 64 bytes of the row (one 144 KB workgroup per CU)
+#define LITHO_COOP_DMA_WAVES 4
+#endif
+                constexpr int ND = LITHO_COOP_DMA_WAVES;
                 static LdsOnce once_dma;
-                auto kd = k_ypass_coop_dma<LOG2N, NW>;
-                hipError_t ed = set_lds(once_dma, kd, CoopDmaShape<NW>::LDS_BYTES);
+                auto kd = k_ypass_coop_dma<LOG2N, ND>;
+                hipError_t ed = set_lds(once_dma, kd, CoopDmaShape<ND>::LDS_BYTES);
                 if (ed != hipSuccess) return ed;
-                hipLaunchKernelGGL(kd, dim3(CoopDmaShape<NW>::grid_x(g.pn), planes * G), dim3(64 * NW), CoopDmaShape<NW>::LDS_BYTES, st, T,
+                hipLaunchKernelGGL(kd, dim3(CoopDmaShape<ND>::grid_x(g.pn), planes * G), dim3(64 * ND), CoopDmaShape<ND>::LDS_BYTES, st, T,
                                    slab, tw, g, nb, G, gstride);
-                note_kernel(1, "k_ypass_coop_dma<%d, %d>", LOG2N, NW);
+                note_kernel(1, "k_ypass_coop_dma<%d, %d>", LOG2N, ND);
                 return hipGetLastError();
             }
             static LdsOnce once;

@@ -286,3 +286,52 @@ int main() {
         subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(d, "t.cpp"), "-o", os.path.join(d, "t")])
         r = subprocess.run([os.path.join(d, "t")], capture_output=True, text=True)
         assert r.returncode == 0 and r.stdout.strip() == "0", (r.returncode, r.stdout, r.stderr)
+
+
+def test_planner_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """The host-only planner compiled with -fsanitize=address,undefined (GPU sanitizers are not available on this pool: the
+    CPU build is where they run) and driven through the same kind of sweep from C++: sizes x FFT sizes x planes x wrapping /
+    non-wrapping extents x a few option sets, 64-bit offset arithmetic at 16384^2 with every pixel lit included.  Any
+    out-of-bounds access, signed overflow or misaligned read in csrc/abbe_plan.hpp / plan_dry_run.cpp aborts the driver."""
+    driver = r'''
+#include <climits>
+#include <cstdio>
+#include <cstring>
+#include <initializer_list>
+#include "%(hdr)s"
+int main() {
+    long plans = 0, bad = 0;
+    const int sizes[] = {2, 6, 30, 64, 96, 200, 256, 300, 512, 1000, 1024, 1500, 2048, 3000, 4094, 4096, 6000, 8192, 12000, 16382, 16384};
+    for (int pn : sizes) for (int N = 16; N <= 16384; N *= 2) {
+        if (N < pn) continue;
+        for (int planes : {1, 3, 32}) for (int wrap = 0; wrap < 2; ++wrap) for (int optset = 0; optset < 4; ++optset) for (long long S : {1LL, 257LL, (long long)pn * pn}) {
+            const int c = pn / 2, h = pn / 4, lim = wrap ? c : (c - h > 0 ? c - h - 1 : 0);
+            if (S > INT_MAX) continue;
+            int32_t w[14] = {c - h, c + h < pn ? c + h : pn - 1, c - h, c + h < pn ? c + h : pn - 1, -lim, lim, -lim, lim, (int32_t)S, c, c, c, c, 0};
+            int32_t sw[10] = {(int32_t)(S / 2), (int32_t)(S - S / 2), -(c - h), lim < c - h ? lim : c - h - 1, -(c - h), 0, -lim, lim, -lim, lim};
+            litho_abbe_options o; memset(&o, 0xFF, sizeof(o)); o.size = sizeof(o);
+            if (optset == 1) { o.coarse = 0; o.tile = 4; o.batch = 1; }
+            if (optset == 2) { o.coarse = 2; o.plane_chunk = 4; o.groups = 64; o.split = 2; }
+            if (optset == 3) { o.force_general = 1; o.embed = 0; o.xchunk = 3; }
+            litho_abbe_dry_run r; memset(&r, 0, sizeof(r)); r.size = sizeof(r);
+            const int rc = litho_abbe_plan_dry_run(pn, N, planes, w, sw, &o, 256, 0, &r);
+            if (rc != 0) { ++bad; continue; }
+            ++plans;
+            for (int p = 0; p < 2; ++p) {
+                const litho_abbe_dry_part& d = r.part[p];
+                if (!d.present || r.status) continue;
+                if (d.T_used.offset + d.T_used.bytes > d.T_region.offset + d.T_region.bytes || d.T_region.offset + d.T_region.bytes > r.workspace_bytes) ++bad;
+            }
+        }
+    }
+    printf("%%ld plans, %%ld bad\n", plans, bad);
+    return bad ? 1 : 0;
+}''' % {"hdr": os.path.join(ROOT, "include", "litho_abbe.h")}
+    src = tmp_path / "sweep.cpp"
+    src.write_text(driver)
+    exe = tmp_path / "sweep"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
+                           str(src), os.path.join(ROOT, "lithographysimulator_amd", "csrc", "plan_dry_run.cpp"), "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
+    assert int(r.stdout.split()[0]) > 3000, r.stdout

@@ -386,7 +386,7 @@ static inline int plan_abbe(AbbePlan& pp, size_t t_bytes, const Knobs& kn, const
     int64_t items_cache = (int64_t)(((size_t)208 << 20) / item_bytes);
     // 4096^2 (67 MB per item): not even 8 items fit the cache, T round-trips HBM whatever the batch -- then the batch
     // is as long as the workspace allows (60 items of its 4 GiB: fewer accumulator flushes in the y-pass) and an x-pass
-    // workgroup walks 15 items for its row.  us per source point, coarse-grid path, alternating A/B (round 2, 1 GiB):
+    // workgroup walks 30 items for its row (15 until round 5).  us per source point, coarse-grid path, alternating A/B (round 2, 1 GiB):
     // 8 items x chunks of 4 49.9 / 49.8; 12 x 6 47.9; 12 x 12 45.6; 15 x 5 47.5; 15 x 15 45.3 / 45.2; round 3 (4 GiB):
     // 30 x 15 44.1, 45 x 15 43.5, 60 x 15 43.2, 60 x 60 43.3.
     const bool beyond_cache = items_cache < 8;
@@ -428,7 +428,9 @@ static inline int plan_abbe(AbbePlan& pp, size_t t_bytes, const Knobs& kn, const
         if (want == 2) for (int cand : {2, 3, 1}) if (bs % cand == 0) { xchunk = cand; break; }
         if (beyond_cache && PC == 1) {                         // see above
             xchunk = (int)bs;
-            for (int cand : {15, 12, 16, 10, 20, 8, 6}) if (bs > cand && bs % cand == 0) { xchunk = cand; break; }
+            // (round 5, beside k_ypass_coop_dma, bench.py --workload cfg4 --points 5400, alternating: 15 items per workgroup 195.4 /
+            // 195.8 ms, 20 194.5 / 194.4, 30 194.0 / 194.1, 60 195.2 / 195.6 -- x-pass 13.95 -> 13.64 us per item at 30)
+            for (int cand : {30, 15, 20, 12, 16, 10, 8, 6}) if (bs > cand && bs % cand == 0) { xchunk = cand; break; }
         }
         // 1024-point rows (64-thread workgroups, 16 per CU): longer chunks pay -- coarse-grid x-pass at 1024^2,
         // us per point: chunk 2 1.40, 3 1.27, 4 1.18, 6 1.12, 8 1.20, 12 1.03, 16 1.06, 24 1.34, 48 2.0

@@ -611,7 +611,7 @@ def test_config4_fold_run_vs_golden(golden, L, dev, path):
         assert (kx, ky) == ("k_xpass_split<13>", "k_ypass_pair<13, 8>"), (kx, ky)
         assert plan["launches"] > 64, plan                        # the direct path's batch is shorter: more folds still
     else:
-        assert (plan["batch"], plan["launches"], plan["xchunk"]) == (60, 67, 15), plan
+        assert (plan["batch"], plan["launches"], plan["xchunk"]) == (60, 67, 30), plan
         assert (kx, ky) == ("k_xpass_abbe<12, 0, true, 1, 1>", "k_ypass_coop<12, 4>" if "coopreg" in path else "k_ypass_coop_dma<12, 4>"), (kx, ky)
     final = L.postProcess(raw, eps).cpu()
     raw = raw.cpu()
@@ -639,7 +639,7 @@ def test_consecutive_shard_4096_vs_golden(golden, L, dev, monkeypatch, path):
     4094^2 post-processed image (quirk Q5), default (coarse-grid: 16-column T tiles, k_ypass_coop_dma -- the next line prefetched
     by LDS-DMA, round 5 -- and, "coopreg", its round-3 predecessor k_ypass_coop loading through registers) and direct evaluation,
     and the coarse grid on 8-column tiles (k_ypass_wave<12, 8, true>; with and without the row-pair x-pass).  The
-    "-default-batch" runs leave the launch geometry to the planner, as a caller gets it: ONE 60-item batch with 15-point
+    "-default-batch" runs leave the launch geometry to the planner, as a caller gets it: ONE 60-item batch with 30-point
     x-pass chunks plus a ragged batch of 4 (asserted) -- config 4's production geometry on the reference's dense data."""
     from lithographysimulator_amd import _native as nat
     from lithographysimulator_amd.synthetic import bernoulli_mask
@@ -665,7 +665,7 @@ def test_consecutive_shard_4096_vs_golden(golden, L, dev, monkeypatch, path):
     plan = nat.last_plan()
     assert plan["coarse_grid"] == (1 if path.startswith("coarse") else 0) and plan["launches"] >= (2 if default_batch else 4), plan
     if default_batch:
-        assert (plan["batch"], plan["launches"], plan["xchunk"]) == (60, 2, 15), plan
+        assert (plan["batch"], plan["launches"], plan["xchunk"]) == (60, 2, 30), plan
     kx, ky = nat.last_kernels()
     if path.startswith("coarse"):
         want = "k_ypass_wave<12, 8, true>" if "tile8" in path else ("k_ypass_coop<12, 4>" if "coopreg" in path else "k_ypass_coop_dma<12, 4>")

@@ -139,7 +139,7 @@ def test_baseline_configurations_plan_as_documented(nat, coarse):
             if batch:
                 assert p.batch == batch, (pn, p.batch)
             if pn == 4096:
-                assert p.xchunk == 15 and p.T_used.bytes == 60 * 2049 * 4096 * 8
+                assert p.xchunk == 30 and p.T_used.bytes == 60 * 2049 * 4096 * 8
 
 
 def test_embedded_sizes(nat):

@@ -631,7 +631,7 @@ def main():
         torch.cuda.empty_cache()
         extras = []
         for name, kw in (("cfg1", dict(steps=5, profile_points=1 << 30)), ("cfg2", dict(steps=2, profile_points=4800)),
-                         ("cfg4", dict(shard=(0, 8), steps=1, warm_points=600, profile_points=600)),
+                         ("cfg4", dict(shard=(0, 8), steps=1, warm_points=600, profile_points=2400)),
                          ("cfg5", dict(steps=1, warm_points=240, profile_points=240)),
                          ("odd2000", dict(steps=1, warm_points=480, profile_points=480))):
             try:

@@ -161,10 +161,11 @@ def test_embedded_sizes(nat):
             check_result(res, pn, ps_N, planes, f"embedded-refused pn {pn}")
             assert res.nowrap == 0 and res.part[0].run_size == pn and res.part[0].general == 1 and res.part[0].embed_M.bytes == 0
             # an older, smaller workspace (the own-size regions only)
-            own = ctypes.c_size_t(0)
             small = nat.plan_dry_run(pn, ps_N, planes, disk_words(pn, 5000, (-q, q), (-q, q)), options={"embed": 0})
             assert small.part[0].run_size == pn and small.part[0].embed_M.bytes == 0
-            del own
+            # ... and so does a caller-provided workspace that only holds the own-size regions (an older, smaller workspace)
+            own_only = nat.plan_dry_run(pn, ps_N, planes, disk_words(pn, 5000, (-q, q), (-q, q)), workspace_bytes=small.part[0].T_region.end)
+            assert own_only.status == 0 and own_only.part[0].run_size == pn and own_only.part[0].embed_M.bytes == 0
 
 
 def test_split_source_lists(nat):
@@ -245,8 +246,7 @@ def test_planner_header_compiles_without_hip(tmp_path):
     into a library that exports the entry point."""
     out = tmp_path / "libplan_only.so"
     src = os.path.join(ROOT, "lithographysimulator_amd", "csrc", "plan_dry_run.cpp")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-shared", "-fPIC", "-nostdinc++" if False else "-fno-exceptions",
-                           src, "-o", str(out)])
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-shared", "-fPIC", src, "-o", str(out)])
     lib = ctypes.CDLL(str(out))
     assert hasattr(lib, "litho_abbe_plan_dry_run")
     deps = subprocess.run(["ldd", str(out)], capture_output=True, text=True).stdout

@@ -96,7 +96,29 @@ struct WaveSq {
     static_assert(LS == 5 || LS == 6, "S = 32 or 64");
     static constexpr int S = 1 << LS;                 // lanes per line = slots per lane
     static constexpr int LINES = 64 / S;              // lines per wave
-    static constexpr int LDS_FLOATS = 64 * (S + 1);   // LINES padded S x S fp32 matrices per wave
+    // Row stride of the transpose matrix in floats.  S + 1 (odd: column reads and row writes conflict-free with 4-byte ops) -- or,
+    // build-time experiment LITHO_TSTRIDE=68 for S = 64: a multiple of 4, so that a lane writes its row with 16-byte LDS stores
+    // (ds_write_b128, 16 per phase instead of 32 ds_write2_b32; a 16-lane group covers all 64 banks) while the column reads stay
+    // conflict-free (bank = (4 r + lane) mod 64 for a fixed row r).
+#ifndef LITHO_TSTRIDE
+#define LITHO_TSTRIDE 0
+#endif
+    static constexpr int TS = (LS == 6 && LITHO_TSTRIDE) ? LITHO_TSTRIDE : S + 1;
+    static constexpr int LDS_FLOATS = 64 * TS;        // LINES padded S x S fp32 matrices per wave
+    // one row of the matrix: S floats from consecutive compile-time slots, 4 at a time when the stride allows aligned 16-byte stores
+    template <typename Get>
+    __device__ static __forceinline__ void write_row(float* wr, Get&& get)
+    {
+        if constexpr (TS % 4 == 0) {
+            static_for<0, S / 4>([&](auto k_) {
+                constexpr int k = decltype(k_)::value;
+                *reinterpret_cast<float4*>(wr + 4 * k) = make_float4(get(std::integral_constant<int, 4 * k>{}), get(std::integral_constant<int, 4 * k + 1>{}),
+                                                                      get(std::integral_constant<int, 4 * k + 2>{}), get(std::integral_constant<int, 4 * k + 3>{}));
+            });
+        } else {
+            static_for<0, S>([&](auto m_) { wr[decltype(m_)::value] = get(m_); });
+        }
+    }
     static constexpr int NTW = 8 + S / 8;             // lane twiddle factors
 
     __host__ __device__ static constexpr int brev(int v)
@@ -221,22 +243,22 @@ struct WaveSq {
         const int l = lane & (S - 1), line = lane >> LS;
         // S x S transpose, real parts then imaginary parts, through this line's private matrix:
         // element (row = writer lane, col = m); reader lane m takes column m.
-        float* const mat = lds + line * (S * (S + 1));
-        float* const wr = mat + l * (S + 1);
+        float* const mat = lds + line * (S * TS);
+        float* const wr = mat + l * TS;
         float* const rd = mat + l;
-        static_for<0, S>([&](auto m_) { constexpr int m = decltype(m_)::value; wr[m] = x[brev(m)].x; });
+        write_row(wr, [&](auto m_) { return x[brev(decltype(m_)::value)].x; });
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         float re[S];
-        static_for<0, S>([&](auto r_) { constexpr int r = decltype(r_)::value; re[r] = rd[r * (S + 1)]; });
+        static_for<0, S>([&](auto r_) { constexpr int r = decltype(r_)::value; re[r] = rd[r * TS]; });
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        static_for<0, S>([&](auto m_) { constexpr int m = decltype(m_)::value; wr[m] = x[brev(m)].y; });
+        write_row(wr, [&](auto m_) { return x[brev(decltype(m_)::value)].y; });
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         static_for<0, S>([&](auto r_) {
             constexpr int r = decltype(r_)::value;
-            x[r] = make_float2(re[r], rd[r * (S + 1)]);
+            x[r] = make_float2(re[r], rd[r * TS]);
         });
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -268,21 +290,21 @@ struct WaveSq {
 #ifdef LITHO_TRANSPOSE_OPAQUE
         asm volatile("" : "+v"(lane));
 #endif
-        float* const wr = lds + lane * (S + 1);
+        float* const wr = lds + lane * TS;
         float* const rd = lds + lane;
-        static_for<0, S>([&](auto c_) { constexpr int c = decltype(c_)::value; wr[c] = x[slot_of(c)].x; });
+        write_row(wr, [&](auto c_) { return x[slot_of(decltype(c_)::value)].x; });
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         float re[S];
-        static_for<0, S>([&](auto r_) { constexpr int r = decltype(r_)::value; re[r] = rd[r * (S + 1)]; });
+        static_for<0, S>([&](auto r_) { constexpr int r = decltype(r_)::value; re[r] = rd[r * TS]; });
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        static_for<0, S>([&](auto c_) { constexpr int c = decltype(c_)::value; wr[c] = x[slot_of(c)].y; });
+        write_row(wr, [&](auto c_) { return x[slot_of(decltype(c_)::value)].y; });
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         static_for<0, S>([&](auto r_) {
             constexpr int r = decltype(r_)::value;
-            x[r] = make_float2(re[r], rd[r * (S + 1)]);
+            x[r] = make_float2(re[r], rd[r * TS]);
         });
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -314,23 +336,23 @@ struct WaveSq {
             if constexpr (b != 0) x[sl] = cmul(x[sl], tw.row[b]);
             if constexpr (a != 0) x[sl] = cmul(x[sl], tw.row[8 + a]);
         });
-        float* const wr = mat_own + lane * (S + 1);
+        float* const wr = mat_own + lane * TS;
         const float* const rd0 = (par ? mat_other : mat_own) + lane;      // B_0: wave 0's matrix
         const float* const rd1 = (par ? mat_own : mat_other) + lane;      // B_1: wave 1's matrix
         const float sgn = par ? -1.f : 1.f;
-        static_for<0, S>([&](auto m_) { constexpr int m = decltype(m_)::value; wr[m] = x[brev(m)].x; });
+        write_row(wr, [&](auto m_) { return x[brev(decltype(m_)::value)].x; });
         lds_barrier();
         float re[S];
         static_for<0, S>([&](auto r_) {
             constexpr int r = decltype(r_)::value;
-            re[r] = fmaf(sgn, rd1[r * (S + 1)], rd0[r * (S + 1)]);
+            re[r] = fmaf(sgn, rd1[r * TS], rd0[r * TS]);
         });
         lds_barrier();
-        static_for<0, S>([&](auto m_) { constexpr int m = decltype(m_)::value; wr[m] = x[brev(m)].y; });
+        write_row(wr, [&](auto m_) { return x[brev(decltype(m_)::value)].y; });
         lds_barrier();
         static_for<0, S>([&](auto r_) {
             constexpr int r = decltype(r_)::value;
-            x[r] = make_float2(re[r], fmaf(sgn, rd1[r * (S + 1)], rd0[r * (S + 1)]));
+            x[r] = make_float2(re[r], fmaf(sgn, rd1[r * TS], rd0[r * TS]));
         });
         lds_barrier();
         if (par) static_for<1, S>([&](auto r_) { constexpr int r = decltype(r_)::value; x[r] = mul_root128<r>(x[r]); });

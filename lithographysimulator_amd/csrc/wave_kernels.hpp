@@ -226,7 +226,8 @@ template <int NW>
 struct CoopShape {
     static_assert(NW == 4, "four waves share four columns (32 bytes) of a tile row");
     static constexpr int S = 64, N = 4096, JLIVE = 16, NLIVE = 2 * JLIVE + 1;       // live slots: j <= 16 and j >= 48
-    static constexpr int WAVE_FLOATS = NLIVE * 64 * 2 + 16;                         // staging (33 x 64 float2) >= the 64 x 65 matrix; 64-byte skew between areas
+    static constexpr int STAGE_FLOATS = NLIVE * 64 * 2 + 16;                        // staging (33 x 64 float2); 64-byte skew between areas
+    static constexpr int WAVE_FLOATS = STAGE_FLOATS >= WaveSq<6>::LDS_FLOATS ? STAGE_FLOATS : WaveSq<6>::LDS_FLOATS + 16;   // ... or the transpose matrix, if larger
     static_assert(WAVE_FLOATS >= WaveSq<6>::LDS_FLOATS, "the staging area holds the transpose matrix");
     static constexpr size_t LDS_BYTES = NW * (size_t)WAVE_FLOATS * sizeof(float) + (size_t)WaveSq<6>::TW_LDS_FLOAT2 * sizeof(float2);
     static constexpr int PARTS = 16 / NW;                                           // workgroups per 16-column tile

@@ -44,7 +44,7 @@ template <int TC, int AUX> static void run(float2* T, int rows, int cols, int it
 }
 template <int AUX> static void sweep(float2* T, int rows, int cols, int items)
 {
-    run<4, AUX>(T, rows, cols, items); run<8, AUX>(T, rows, cols, items); run<16, AUX>(T, rows, cols, items); run<64, AUX>(T, rows, cols, items);
+    run<4, AUX>(T, rows, cols, items); run<8, AUX>(T, rows, cols, items); run<16, AUX>(T, rows, cols, items); run<32, AUX>(T, rows, cols, items); run<64, AUX>(T, rows, cols, items); run<256, AUX>(T, rows, cols, items);
 }
 int main()
 {

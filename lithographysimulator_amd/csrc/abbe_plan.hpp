@@ -74,12 +74,18 @@ struct EdgeGeom {
 };
 
 // y-pass groups = private partial images (slabs).  Up to 8 for large images; small images can afford more
-// (their y-pass grid would otherwise be a handful of workgroups): as many as fit in 128 MiB, at most 64.
+// (their y-pass grid would otherwise be a handful of workgroups): as many as fit in 128 MiB, at most LITHO_G_CAP = 128.
+// (64 until round 5: at 256^2 the coarse-grid y-pass -- 64 columns per workgroup, two groups per 512-thread workgroup -- was then
+// a grid of 4 x 32 = 128 workgroups on 256 CUs; with 128 groups every CU has one: y-pass 70 -> 50 us per 809-item launch,
+// config 1 0.593 -> 0.523 ms per image in three alternating A/B pairs.)
+#ifndef LITHO_G_CAP
+#define LITHO_G_CAP 128
+#endif
 static inline int g_cap(int pn)
 {
     const size_t one = (size_t)((pn + 3) / 4) * 4 * pn * sizeof(float);
     size_t n = ((size_t)128 << 20) / one;
-    return n < 8 ? 8 : (n > 64 ? 64 : (int)n);
+    return n < 8 ? 8 : (n > LITHO_G_CAP ? LITHO_G_CAP : (int)n);
 }
 static constexpr int SLAB_FLUSH_BATCHES = 64;
 static constexpr size_t T_BUDGET_MAX = (size_t)1 << 30;

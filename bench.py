@@ -273,7 +273,7 @@ def measured_ceilings(torch, dev):
 # once-per-image reconstruction do not shrink -- plus ONE all-reduce priced per xGMI link (ring: 2 (N-1)/N of the buffer through
 # ~100 GB/s effective per direction).  single_gpu_ms: measured on one MI355X this round (profiles/r05_bench*.json; cfg4 = 8 x its
 # measured shard); fixed_ms: plan read-back + coarse-grid reconstruction + post-process, which every rank repeats.
-PREDICTION = {"cfg1": {"single_gpu_ms": 0.63, "fixed_ms": 0.25}, "cfg2": {"single_gpu_ms": 194.0, "fixed_ms": 0.6},
+PREDICTION = {"cfg1": {"single_gpu_ms": 0.55, "fixed_ms": 0.25}, "cfg2": {"single_gpu_ms": 194.0, "fixed_ms": 0.6},
               "cfg3": {"single_gpu_ms": 1680.0, "fixed_ms": 1.5}, "cfg4": {"single_gpu_ms": 55600.0, "fixed_ms": 6.0},
               "cfg5": {"single_gpu_ms": 53900.0, "fixed_ms": 40.0}}
 XGMI_EFFECTIVE_GBS = 100.0

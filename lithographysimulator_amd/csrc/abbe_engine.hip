@@ -411,13 +411,34 @@ const SizeOps* size_ops(int log2n)
     }
 }
 
-// Reads the plan words back (one small synchronising copy).
-static int read_plan(const Workspace& w, int host[PLAN_WORDS], hipStream_t st)
+// A few dozen ints of PINNED host memory per calling thread for the read-backs (plan words, the split's ten words).  Into
+// pageable memory (a stack array) the runtime stages the 56 bytes through a blit kernel and a bounce buffer: 44 us on the
+// device timeline of a config-1 image (rocprofv3: __amd_rocclr_copyBuffer), a twelfth of the whole image; nullptr if the
+// allocation fails (then the stack array is used as before).  Never freed: a thread's buffer lives as long as the process.
+static int* pinned_words()
 {
-    HIP_TRY(hipMemcpyAsync(host, w.plan, PLAN_WORDS * sizeof(int), hipMemcpyDeviceToHost, st));
+    static thread_local int* p = nullptr;
+    static thread_local bool tried = false;
+    if (!tried) {
+        tried = true;
+        void* q = nullptr;
+        if (hipHostMalloc(&q, 64 * sizeof(int), hipHostMallocPortable) == hipSuccess) p = (int*)q;
+        else (void)hipGetLastError();
+    }
+    return p;
+}
+// n ints from the device to `host` (one small synchronising copy)
+static int read_words(const int* dev, int* host, int n, hipStream_t st)
+{
+    int* pin = pinned_words();
+    int* dst = (pin && n <= 64) ? pin : host;
+    HIP_TRY(hipMemcpyAsync(dst, dev, n * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (dst != host) memcpy(host, dst, n * sizeof(int));
     return LITHO_OK;
 }
+// Reads the plan words back.
+static int read_plan(const Workspace& w, int host[PLAN_WORDS], hipStream_t st) { return read_words(w.plan, host, PLAN_WORDS, st); }
 
 // HIP events of one profiled call; destroyed on every exit path.
 struct Mark { hipEvent_t ev; int kind; int items; };   // kind: -1 start, 0 after an x-pass, 1 after a y-pass
@@ -733,8 +754,8 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
             hipLaunchKernelGGL(k_split_write, dim3(nblocks), dim3(256), 0, st, shifts, (long long)S, box, counts, list_a, list_b, words);
             HIP_TRY(hipGetLastError());
             if (!from_record) {
-                HIP_TRY(hipMemcpyAsync(sw, words, sizeof(sw), hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
+                rc = read_words(words, sw, 10, st);
+                if (rc) return rc;
                 if (reuse) record_store(reuse->words, pl, pe, sw);
             }
             int64_t launches = 0;

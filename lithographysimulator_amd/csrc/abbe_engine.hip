@@ -126,17 +126,19 @@ __global__ void k_shift_extents(const int* __restrict__ shifts, long long S, con
     }
 }
 
-// out[p][qy][qx] += sum_g slab[p * gstride + g][qx][qy]   (32x32 tiles through LDS; blockIdx.z = plane p).  1024 threads per
-// tile, one element each: small images fold up to 64 slabs into a few dozen tiles (256^2: 64 tiles), and with 256 threads
-// walking four rows each that took 38 us per image; fixed summation order (deterministic).
-__global__ __launch_bounds__(1024) void k_slab_reduce(const float* __restrict__ slab, float* __restrict__ out, int pn, int ldq, int G,
-                                                      int gstride)
+// out[p][qy][qx] += sum_g slab[p * gstride + g][qx][qy]   (TS x TS tiles through LDS; blockIdx.z = plane p).  TS * TS threads per
+// tile, one element each: small images fold up to 64 slabs into a few dozen tiles (256^2: 64 tiles of 32 x 32), and with 256 threads
+// walking four rows each that took 38 us per image; fixed summation order (deterministic).  TS = 16 where 32 x 32 tiles would
+// not give every CU a workgroup (round 5: 256^2 folds 64 slabs in 64 workgroups otherwise -- 20 us of a 500 us image).
+template <int TS>
+__global__ __launch_bounds__(TS * TS) void k_slab_reduce(const float* __restrict__ slab, float* __restrict__ out, int pn, int ldq, int G,
+                                                         int gstride)
 {
-    __shared__ float tile[32][33];
+    __shared__ float tile[TS][TS + 1];
     slab += (size_t)blockIdx.z * gstride * ldq * pn;
     out += (size_t)blockIdx.z * pn * pn;
-    const int qx0 = blockIdx.x * 32, qy0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 1024 threads: ty in 0..31
+    const int qx0 = blockIdx.x * TS, qy0 = blockIdx.y * TS;
+    const int tx = threadIdx.x % TS, ty = threadIdx.x / TS;
     {
         const int qx = qx0 + ty, qy = qy0 + tx;
         float v = 0.f;
@@ -147,6 +149,15 @@ __global__ __launch_bounds__(1024) void k_slab_reduce(const float* __restrict__ 
     __syncthreads();
     const int qy = qy0 + ty, qx = qx0 + tx;
     if (qx < pn && qy < pn) out[(size_t)qy * pn + qx] += tile[tx][ty];
+}
+static hipError_t launch_slab_reduce(const float* slab, float* out, int pn, int ldq, int planes, int G, int gstride, hipStream_t st)
+{
+    const int t32 = (pn + 31) / 32;
+    if ((long long)t32 * t32 * planes >= device_cus())
+        hipLaunchKernelGGL(k_slab_reduce<32>, dim3(t32, t32, planes), dim3(1024), 0, st, slab, out, pn, ldq, G, gstride);
+    else
+        hipLaunchKernelGGL(k_slab_reduce<16>, dim3((pn + 15) / 16, (pn + 15) / 16, planes), dim3(256), 0, st, slab, out, pn, ldq, G, gstride);
+    return hipGetLastError();
 }
 
 // ----------------------------------------------------------------------------------
@@ -548,17 +559,13 @@ static int accumulate_chunk(const AbbePlan& pp, const SizeOps* ops, const Worksp
         // float64 sum of short runs: 5.4e-6 of the maximum with one slab sum over all 16,509 batches, see
         // scripts/accum_error_probe.py).  Costs one k_slab_reduce + memset per 64 launch pairs (< 0.5 %).
         if (++since_flush == SLAB_FLUSH_BATCHES && s0 + bs < S) {
-            hipLaunchKernelGGL(k_slab_reduce, dim3((pn + 31) / 32, (pn + 31) / 32, pc), dim3(1024), 0, st,
-                               w.slab, dst, pn, g.nt * 4, pp.slabs, G);
-            HIP_TRY(hipGetLastError());
+            HIP_TRY(launch_slab_reduce(w.slab, dst, pn, g.nt * 4, pc, pp.slabs, G, st));
             HIP_TRY(zero_slabs(w.slab, pc, G, pp.slabs, slab_plane, st));
             since_flush = 0;
             fresh = true;
         }
     }
-    hipLaunchKernelGGL(k_slab_reduce, dim3((pn + 31) / 32, (pn + 31) / 32, pc), dim3(1024), 0, st,
-                       w.slab, dst, pn, g.nt * 4, pp.slabs, G);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_slab_reduce(w.slab, dst, pn, g.nt * 4, pc, pp.slabs, G, st));
     return LITHO_OK;
 }
 

@@ -567,7 +567,7 @@ def main():
     fabric_gbs = traffic / dom_s / 1e9 if traffic and dom_s > 0 else None
     # "bound" takes the contract's two values ("hbm" | "mfma"): this is the flop side -- priced against the dense fp32 peak,
     # 157.3 TFLOP/s, which on gfx950 is the same figure for the matrix and the vector pipe; `bound_detail` says which pipe
-    roofline = {"bound": "mfma", "bound_detail": "VALU: fp32 vector issue, NOT the matrix pipe -- the path has no MFMA instruction; \"mfma\" is the "
+    roofline = {"bound": "mfma", "bound_measured": "valu", "bound_detail": "VALU: fp32 vector issue, NOT the matrix pipe -- the path has no MFMA instruction; \"mfma\" is the "
                                                   "contract's name for the flop side, priced at the dense fp32 peak, which on gfx950 is "
                                                   "157.3 TFLOP/s for the vector and the matrix pipe alike", "kernel": kern[dom]["kernel"],
                 "achieved": kern[dom]["achieved_TFLOPs"], "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -712,25 +712,26 @@ def test_seeded_fuzz_against_the_float64_oracle(L, dev):
 # k_xpass_split<13>, k_ypass_pair -- the kernels that carry configs 2-5.)  Same pupil families, random options incl. the
 # 4096-only ones, pre-filled `out`, NaN-poisoned scratch, 1-2 source points x 1-3 planes, against the float64 closed form
 # (O(pn^3) per point: the host's zgemm does a 2048^2 point in a fraction of a second).
-def _fuzz_case_mid(seed, sizes):
+def _fuzz_case_mid(seed, sizes, coarse=None, mode=None, kind=None, fixed=None):
     gen = torch.Generator().manual_seed(7700000 + seed)
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=gen))          # noqa: E731
     pick = lambda seq: seq[ri(0, len(seq) - 1)]                                      # noqa: E731
     pn = pick(sizes)
-    kind = pick(["disk", "disk", "disk", "disk", "disk_rim", "disk_rim", "disk_junk", "disk_junk", "box", "single"])
+    kind = pick(["disk", "disk", "disk", "disk", "disk_rim", "disk_rim", "disk_junk", "disk_junk", "box", "single"]) if kind is None else kind
     planes = pick([1, 1, 1, 2, 3]) if pn < 4096 else pick([1, 1, 2])
     S = pick([1, 2, 2]) if pn < 4096 else 1 if planes > 1 else pick([1, 2])
     c, h = pn // 2, pn // 4
-    mode = pick(["narrow", "narrow", "narrow", "wide", "wide", "wrap"])
+    mode = mode or pick(["narrow", "narrow", "narrow", "wide", "wide", "wrap"])
     lim = {"narrow": max(1, int(0.2 * pn)), "wide": c - h, "wrap": c}[mode]
     sh = torch.randint(-lim, lim + (0 if mode == "wrap" else 1), (S, 2), generator=gen, dtype=torch.int32)
-    opts = {"poison": 1, "coarse": pick([0, 2, 2, 2, 1])}
+    opts = {"poison": 1, "coarse": pick([0, 2, 2, 2, 1]) if coarse is None else coarse}
     for name, values in (("batch", [0, 0, 1, 2, 3]), ("groups", [0, 0, 0, 1, 2, 4]), ("xchunk", [0, 0, 1, 2]),
                          ("tile", [0, 0, 0, 4, 8] + ([16] if pn == 4096 else [])), ("plane_chunk", [0, 1, 2, 4]), ("gcombine", [1, 1, 0]),
                          ("rect", [1, 1, 1, 0]), ("w64", [1, 1, 1, 1, 0]), ("xrect", [1, 1, 0, 2]), ("force_generic", [0, 0, 0, 0, 1]),
                          ("force_general", [0, 0, 0, 0, 0, 1]), ("split", [1, 2, 2, 0]), ("xsplit", [1, 1, 0]), ("w64_8192", [1, 1, 0]),
                          ("coopdma", [1, 1, 0]), ("rowpairs", [0, 0, 1])):
         opts[name] = pick(values)
+    opts.update(fixed or {})
     pupils = torch.stack([_fuzz_pupil(gen, kind, pn) for _ in range(planes)])
     mft = torch.complex(torch.randn(pn, pn, generator=gen), torch.randn(pn, pn, generator=gen))
     prefill = torch.rand(planes, pn, pn, generator=gen) if ri(0, 1) else torch.zeros(planes, pn, pn)
@@ -739,16 +740,33 @@ def _fuzz_case_mid(seed, sizes):
 
 
 def test_seeded_fuzz_mid_sizes_against_the_float64_oracle(L, dev):
-    paths, kernels = _run_fuzz(L, dev, [_fuzz_case_mid(seed, [1024, 1024, 2048]) for seed in range(48)], "fuzz 1024/2048")
+    cases = [_fuzz_case_mid(seed, [1024, 1024, 2048]) for seed in range(48)]
+    # the random options and pupil families leave the coarse grid most of the time (no wave kernels, generic kernels, long rims,
+    # junk beyond the natural box): twelve more that stay on it -- disks, every launch-geometry option still random
+    keep = {"w64": 1, "rect": 1, "force_generic": 0, "force_general": 0, "tile": 0}
+    cases += [_fuzz_case_mid(500 + seed, [1024, 2048], coarse=2, mode=("narrow", "wide")[seed & 1], kind="disk", fixed=keep) for seed in range(12)]
+    paths, kernels = _run_fuzz(L, dev, cases, "fuzz 1024/2048")
     fams = {k[0] for k in paths}
-    assert {"coarse", "direct"} <= fams and any(k[1] == "wave" for k in paths), paths
+    assert {"coarse", "direct"} <= fams and paths.get(("coarse", "wave", 1), 0) >= 16, paths
     # the kernels of BASELINE configs 2, 3 and 5 (coarse grid) and their direct-path counterparts must have been reached
     for must in ("k_ypass_rect<10, 8, true", "k_ypass_rect<11, 8, true", "k_xpass_abbe<10, 0, true", "k_xpass_abbe<11, 0, true"):
         assert any(k.startswith(must) for k in kernels), (must, sorted(kernels))
 
 
 def test_seeded_fuzz_4096_against_the_float64_oracle(L, dev):
-    paths, kernels = _run_fuzz(L, dev, [_fuzz_case_mid(1000 + seed, [4096]) for seed in range(10)], "fuzz 4096")
-    assert any(k[0] == "coarse" for k in paths), paths
-    # config 4's kernels: the coarse grid's cooperative y-pass (either loader) and the 4096-point x-pass
+    cases = [_fuzz_case_mid(1000 + seed, [4096]) for seed in range(10)]
+    # ... and four on the DIRECT path with non-wrapping shifts (N = 8192: k_xpass_split + k_ypass_pair, or their radix-16
+    # counterparts when the options say so), which the ten random draws above happen not to reach
+    cases += [_fuzz_case_mid(1100 + seed, [4096], coarse=0, mode=("narrow", "wide")[seed & 1]) for seed in range(4)]
+    # ... and six of which the disks STAY on the coarse grid (the random options and pupil families above leave it nine times out of ten: no
+    # wave kernels, generic kernels, rims longer than 128 samples): disk / junk pupils, everything else random -- batch, groups,
+    # chunk, planes in flight, the loader of the cooperative y-pass, tile 16 or automatic
+    keep = {"w64": 1, "force_generic": 0, "force_general": 0, "rowpairs": 0}
+    cases += [_fuzz_case_mid(1200 + seed, [4096], coarse=2, mode=("narrow", "wide")[seed & 1], kind=("disk", "disk", "disk_junk")[seed % 3],
+                             fixed=dict(keep, tile=(0, 16)[seed % 2])) for seed in range(6)]
+    paths, kernels = _run_fuzz(L, dev, cases, "fuzz 4096")
+    assert paths.get(("coarse", "wave", 1), 0) >= 4 and any(k[0] == "direct" for k in paths), paths
+    # config 4's kernels: the coarse grid's cooperative y-pass (either loader) and the 4096-point x-pass; the direct path's
+    # 8192-point kernels
     assert any(k.startswith("k_ypass_coop") for k in kernels) and any(k.startswith("k_xpass_abbe<12, 0, true") for k in kernels), sorted(kernels)
+    assert any(k.startswith(("k_xpass_split<13>", "k_ypass_pair<13", "k_ypass_acc<13", "k_xpass_abbe<13")) for k in kernels), sorted(kernels)

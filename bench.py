@@ -521,7 +521,10 @@ def main():
         props = torch.cuda.get_device_properties(dev)
         ident = f"{props.name} pci {getattr(props, 'pci_domain_id', 0):04x}:{getattr(props, 'pci_bus_id', 0):02x}:{getattr(props, 'pci_device_id', 0):02x} cuda:{dev.index}"
         idents = [None] * world
-        dist.all_gather_object(idents, ident)
+        try:
+            dist.all_gather_object(idents, ident)
+        except Exception as exc:                                  # identities are a diagnostic: never cost the measurement
+            idents = [f"unavailable: {exc!r}"] * world
         try:
             rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
         except Exception:
@@ -531,7 +534,7 @@ def main():
                  "step_ms_max": max(r[0] for r in rows), "step_ms_min": min(r[0] for r in rows),
                  "allreduce_bytes": int(part.numel() * 4),
                  "world": dist.get_world_size(), "backend": backend + (" (RCCL)" if backend == "nccl" else ""), "rccl_version": rccl,
-                 "devices": idents, "distinct_devices": len(set(idents)),
+                 "devices": idents, "distinct_devices": len(set(idents)) if not str(idents[0]).startswith("unavailable") else None,
                  "note": "step_ms = each rank's own mean over the timed steps; compute_ms (HIP events) and "
                          "allreduce_wait_ms (host clock from this rank's compute done to its all-reduce done: "
                          "collective + waiting for the slowest rank) from one extra instrumented step"}

@@ -707,8 +707,9 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     }
     hipLaunchKernelGGL(k_twiddle_table, dim3((N + 255) / 256), dim3(256), 0, st, w.twtab, N);
     int pl[PLAN_WORDS];
-    // (record word 14 = the grid the edge words were looked up for: a record made with the embedding off, or with a smaller
-    // workspace, is not reused for an embedded run and vice versa)
+    // (the record names the grid the edge words were looked up for -- record_run_size: a record made with the embedding off, or
+    // with a smaller workspace, is not reused for an embedded run and vice versa -- and carries a format tag: words another
+    // library version wrote are ignored and the call plans afresh)
     const bool from_record = reuse && reuse->valid == 1 && reuse->pn == pn && reuse->N == N && reuse->planes == planes &&
                              record_is_ours(reuse->words) && record_count(reuse->words) <= S && record_run_size(reuse->words) == pe;
     int sw[10];

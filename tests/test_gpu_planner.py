@@ -461,6 +461,14 @@ def test_planned_calls_keep_the_split_of_a_shifted_source(L, dev):
     # the launches of a planned split: as many as the planning call made
     unplanned = L.abbeIntensity(mft2, pupil, sel, N)
     assert nat().last_plan()["planned_from_record"] == 2 and torch.equal(unplanned, other)
+    # a record this library version did not write (valid flag and sizes right, words without the format tag -- e.g. kept across an
+    # upgrade) is ignored: the call plans afresh instead of unpacking garbage
+    forged = L.PlanCache()
+    forged.record.valid, forged.record.pn, forged.record.N, forged.record.planes = 1, pn, N, 1
+    for i, v in enumerate([128, 384, 128, 384, -10, 10, -10, 10, K, 0, 0, 0, 0, 0, pn, 0]):      # the round-4 layout of the 16 words
+        forged.record.words[i] = v
+    f, _ = L.abbeIntensity(mft, pupil, sel, N, plan=forged)
+    assert nat().last_plan()["planned_from_record"] == 2 and torch.equal(f, first)
     # a record made WITHOUT the split (options) stays unsplit when reused: general path for every point, same image to rounding
     cache0 = L.PlanCache()
     a0, _ = L.abbeIntensity(mft, pupil, sel, N, plan=cache0, options={"split": 0})

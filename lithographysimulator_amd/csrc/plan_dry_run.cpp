@@ -89,6 +89,14 @@ extern "C" int litho_abbe_plan_dry_run(int pn, int N, int planes, const int32_t*
     int pl[PLAN_WORDS];
     for (int i = 0; i < PLAN_WORDS; ++i) pl[i] = plan_words[i];
     const int64_t S = pl[8];
+    // what the planning kernels can produce, nothing else: a support box inside the grid (or the empty box INT_MAX / INT_MIN),
+    // shifts no longer than the grid, a count that fits the grid's pixels, edge supports inside the grid or empty
+    const bool empty_box = pl[1] < pl[0];
+    if (!empty_box && (pl[0] < 0 || pl[1] >= pn || pl[2] < 0 || pl[3] >= pn || pl[3] < pl[2])) return LITHO_E_ARG;
+    if (S < 0 || S > (int64_t)pn * pn) return LITHO_E_ARG;
+    if (S > 0 && (pl[4] > pl[5] || pl[6] > pl[7] || pl[4] < -pn || pl[5] > pn || pl[6] < -pn || pl[7] > pn)) return LITHO_E_ARG;
+    for (int e = 9; e <= 11; e += 2)
+        if (pl[e + 1] >= pl[e] && (pl[e] < 0 || pl[e + 1] >= pn)) return LITHO_E_ARG;
     const int pe = run_size(pn, N, kn, ws_bytes);
     result->run_size = pe;
     const bool nowrap = list_nowrap(pl, pn);
@@ -98,6 +106,11 @@ extern "C" int litho_abbe_plan_dry_run(int pn, int N, int planes, const int32_t*
         const SplitLayout sl = split_layout(pn, pe, N, S);
         if (sl.ok) {
             if (!split_words) return LITHO_E_ARG;
+            if (split_words[0] < 0 || split_words[1] < 0 || (int64_t)split_words[0] + split_words[1] != S) return LITHO_E_ARG;
+            for (int part = 0; part < 2; ++part)
+                if (split_words[part] > 0 && (split_words[2 + 4 * part] > split_words[3 + 4 * part] || split_words[4 + 4 * part] > split_words[5 + 4 * part] ||
+                                              split_words[2 + 4 * part] < -pn || split_words[3 + 4 * part] > pn ||
+                                              split_words[4 + 4 * part] < -pn || split_words[5 + 4 * part] > pn)) return LITHO_E_ARG;
             result->split = 1;
             result->list_a = reg(sl.list_a); result->list_b = reg(sl.list_b); result->split_counts = reg(sl.counts);
             for (int part = 0; part < 2; ++part) {

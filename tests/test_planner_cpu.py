@@ -115,7 +115,7 @@ def test_every_even_size_every_fft_size_every_plane_count(nat):
         for N in admissible_N(pn):
             q = pn // 8                      # sigma_out 0.5-ish: shifts well inside the no-wrap range
             for planes in (1, 2, 5, 32):
-                for S in (1, 300, pn * pn):
+                for S in sorted({1, min(300, pn * pn), pn * pn}):
                     res = nat.plan_dry_run(pn, N, planes, disk_words(pn, S, (-q, q), (-q, q)))
                     checked += check_result(res, pn, N, planes, f"pn {pn} N {N} planes {planes} S {S}")
                     assert res.nowrap == 1 and res.split == 0
@@ -306,7 +306,7 @@ int main() {
         if (N < pn) continue;
         for (int planes : {1, 3, 32}) for (int wrap = 0; wrap < 2; ++wrap) for (int optset = 0; optset < 4; ++optset) for (long long S : {1LL, 257LL, (long long)pn * pn}) {
             const int c = pn / 2, h = pn / 4, lim = wrap ? c : (c - h > 0 ? c - h - 1 : 0);
-            if (S > INT_MAX) continue;
+            if (S > INT_MAX || S > (long long)pn * pn) continue;
             int32_t w[14] = {c - h, c + h < pn ? c + h : pn - 1, c - h, c + h < pn ? c + h : pn - 1, -lim, lim, -lim, lim, (int32_t)S, c, c, c, c, 0};
             int32_t sw[10] = {(int32_t)(S / 2), (int32_t)(S - S / 2), -(c - h), lim < c - h ? lim : c - h - 1, -(c - h), 0, -lim, lim, -lim, lim};
             litho_abbe_options o; memset(&o, 0xFF, sizeof(o)); o.size = sizeof(o);
@@ -334,4 +334,34 @@ int main() {
                            str(src), os.path.join(ROOT, "lithographysimulator_amd", "csrc", "plan_dry_run.cpp"), "-o", str(exe)])
     r = subprocess.run([str(exe)], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
-    assert int(r.stdout.split()[0]) > 3000, r.stdout
+    assert int(r.stdout.split()[0]) > 2800, r.stdout
+
+
+def test_dry_run_rejects_words_the_planning_kernels_cannot_produce(nat):
+    """The dry run validates its inputs (a support box outside the grid, inverted extents, a count beyond pn^2, split counts that
+    do not add up): LITHO_E_ARG, never a plan built on garbage."""
+    pn, N = 512, 1024
+    good = disk_words(pn, 1000, (-20, 20), (-20, 20))
+    assert nat.plan_dry_run(pn, N, 1, good).status == 0
+    for i, v in ((0, -1), (1, pn), (3, pn + 5), (4, 30), (5, -(pn + 1)), (8, pn * pn + 1), (8, -3), (9, -2), (12, pn)):
+        bad = list(good)
+        bad[i] = v
+        with pytest.raises(ValueError):
+            nat.plan_dry_run(pn, N, 1, bad)
+    c, h = pn // 2, pn // 4
+    wrapping = disk_words(pn, 1000, (-(c - h) - 9, 20), (-20, 20))
+    ok_sw = [600, 400, -(c - h), 20, -20, 20, -(c - h) - 9, -(c - h) - 1, -20, 20]
+    assert nat.plan_dry_run(pn, N, 1, wrapping, ok_sw).split == 1
+    for i, v in ((0, 601), (1, -1), (2, 30), (7, pn + 1)):
+        bad = list(ok_sw)
+        bad[i] = v
+        with pytest.raises(ValueError):
+            nat.plan_dry_run(pn, N, 1, wrapping, bad)
+    with pytest.raises(ValueError):
+        nat.plan_dry_run(pn, N, 1, wrapping, None)                  # the call would split: the split's words are required
+    # the empty pupil and the empty list are legal: nothing to add, no part runs
+    empty = [2**31 - 1, -2**31, 2**31 - 1, -2**31] + good[4:]
+    r = nat.plan_dry_run(pn, N, 1, empty)
+    assert r.status == 0 and not r.part[0].present
+    r = nat.plan_dry_run(pn, N, 1, good[:8] + [0] + good[9:])
+    assert r.status == 0 and not r.part[0].present

@@ -26,8 +26,9 @@ Rank 0 prints one JSON line (contract in the task statement) carrying
                   effective: most of those bytes are never moved), `copy_ceiling_GBs` = this box's own 1 GiB copy rate;
   cpu_baseline    (N = 1) the oracle's torch-CPU op chain, i.e. a port of the reference loop, on a bounded sample, with
                   the GPU-vs-CPU parity of that sample taken on the SAME evaluation path the timed step ran;
-  extra_workloads (default run only) one or two timed steps each of config 1, config 2, one rank's shard of config 4
-                  and the config 5 stack, so that every BASELINE configuration has a driver-observed number;
+  extra_workloads (default run only) two or more timed steps each of config 1, config 2, one rank's shard of config 4
+                  and the config 5 stack (mean by host clock + per-step HIP-event times and their median), so that every
+                  BASELINE configuration has a driver-observed number with more than one sample;
   ranks           (N > 1) per-rank step time, compute time and all-reduce time of one instrumented step.
 """
 import argparse
@@ -40,6 +41,7 @@ import statistics
 import subprocess
 import sys
 import time
+from datetime import timedelta
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -72,7 +74,8 @@ GEOMETRY_KEYS = ("batch", "groups_per_plane", "xchunk", "planes_in_flight", "coa
 
 def parse_args():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="number of ranks (default: WORLD_SIZE when launched under torch.distributed.run, else 1)")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS))
@@ -119,6 +122,41 @@ def spawn_ranks(args):
     sys.stdout.write(out0.read())
     sys.stdout.flush()
     sys.exit(worst)
+
+
+RENDEZVOUS_TIMEOUT_S = int(os.environ.get("LITHO_BENCH_TIMEOUT_S", "300"))
+
+
+def die(rank, what, exc=None):
+    """End THIS rank with a non-zero code and its name on stderr (never a re-exec: the process has touched the GPU).
+    os._exit: a process group whose peer is gone can hang in its destructor."""
+    sys.stderr.write(f"bench.py: rank {rank}: {what}" + (f": {exc!r}" if exc is not None else "") + "\n")
+    sys.stderr.flush()
+    sys.stdout.flush()
+    os._exit(3)
+
+
+def check_in(store, rank, world, phase, timeout_s=None):
+    """Bounded host-side rendezvous through the process group's store: every rank posts a key and waits until all keys of the
+    phase are there; after timeout_s the ranks that never arrived are NAMED and this rank exits non-zero -- a missing peer
+    costs minutes, not the lease (a collective would wait for its own, longer, watchdog)."""
+    if store is None:
+        return
+    timeout_s = RENDEZVOUS_TIMEOUT_S if timeout_s is None else timeout_s
+    try:
+        store.set(f"litho_bench/{phase}/{rank}", "1")
+        deadline = time.monotonic() + timeout_s
+        while True:
+            missing = [r for r in range(world) if not store.check([f"litho_bench/{phase}/{r}"])]
+            if not missing:
+                return
+            if time.monotonic() > deadline:
+                die(rank, f"phase '{phase}': rank(s) {missing} of {world} did not arrive within {timeout_s} s")
+            time.sleep(0.002)
+    except SystemExit:
+        raise
+    except Exception as exc:                                     # the store itself is gone: its server rank died
+        die(rank, f"phase '{phase}': rendezvous store unreachable", exc)
 
 
 class Workload:
@@ -367,11 +405,15 @@ def extra_workload(torch, nat, dev, name, shard=None, steps=1, warm_points=0, pr
     else:
         w.step(lo, hi)
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for i in range(steps):
+        marks[i].record()
         image = w.step(lo, hi)
+    marks[steps].record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     plan = nat.last_plan()
     S = hi - lo
     units = float(S) * w.pn * w.pn * w.planes
@@ -386,7 +428,8 @@ def extra_workload(torch, nat, dev, name, shard=None, steps=1, warm_points=0, pr
     both = kern["xpass"]["total_ms"] + kern["ypass"]["total_ms"]
     dom = "ypass" if kern["ypass"]["total_ms"] >= 0.95 * kern["xpass"]["total_ms"] else "xpass"   # as in the headline
     out = {"workload": (f"BASELINE {name}: " if name.startswith("cfg") else f"{name}: ") + w.desc + (f" [{note}]" if note else ""), "steps": steps,
-           "ms_per_step": elapsed / steps * 1e3, "value": units * steps / elapsed, "unit": "source-pt*px/s",
+           "ms_per_step": elapsed / steps * 1e3, "median_ms_per_step": statistics.median(step_ms), "step_ms": step_ms,
+           "value": units * steps / elapsed, "unit": "source-pt*px/s",
            "source_points": S, "source_points_full": w.S_full, "planes": w.planes, "pn": w.pn, "fft_n": w.N,
            "executed_fft_n": n_exec, "image_shape": list(image.shape), "plan": plan,
            "embedded_in": L.embeddedSize(w.pn, w.N) if L.embeddedSize(w.pn, w.N) != w.pn else None,
@@ -423,7 +466,7 @@ def extra_workload(torch, nat, dev, name, shard=None, steps=1, warm_points=0, pr
 
 def main():
     args = parse_args()
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    if "WORLD_SIZE" not in os.environ and (args.gpus or 1) > 1:
         spawn_ranks(args)
 
     import torch
@@ -431,8 +474,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if "WORLD_SIZE" in os.environ and args.gpus != world and not (args.gpus == 1 and world == 1):
-        # a launcher that started another number of ranks than the command line names would silently report the wrong n_gpus
+    if args.gpus is not None and args.gpus != world:
+        # a launcher that started another number of ranks than the command line NAMES would silently report the wrong n_gpus;
+        # without --gpus the launcher's WORLD_SIZE is simply adopted (`torchrun --nproc-per-node N bench.py`)
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node equal to --gpus")
     args.gpus = world
     # Test hooks (tests/test_gpu_bench_contract.py): on a box with ONE GPU the multi-rank code path of this file is
@@ -442,14 +486,28 @@ def main():
     dev = torch.device("cuda", 0 if share_gpu else local_rank)
     torch.cuda.set_device(dev)
     group = None
+    store = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
-        else:
-            dist.init_process_group(backend)
+        # First contact with a multi-GPU node must end in minutes with the guilty rank named, not at the lease limit: the
+        # rendezvous and every collective carry a timeout (RCCL: the process group's watchdog aborts a collective that does not
+        # complete in time), and before the timed region every rank checks in through the rendezvous store (check_in).
+        tmo = timedelta(seconds=RENDEZVOUS_TIMEOUT_S)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev, timeout=tmo)      # "nccl" is RCCL on ROCm
+            else:
+                dist.init_process_group(backend, timeout=tmo)
+        except Exception as exc:
+            die(rank, f"rendezvous of {world} ranks at {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')} failed "
+                      f"within {RENDEZVOUS_TIMEOUT_S} s", exc)
         group = dist.group.WORLD
         assert dist.get_world_size() == world == args.gpus, (dist.get_world_size(), world, args.gpus)
+        try:
+            store = dist.distributed_c10d._get_default_store()
+        except Exception:
+            store = None
+        check_in(store, rank, world, "initialised")
 
     import lithographysimulator_amd as L
     from lithographysimulator_amd import _native as nat
@@ -474,20 +532,31 @@ def main():
     def step():
         return w.step(lo, hi, group=group)
 
-    def fence():
+    def fence(phase=None):
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            if phase:
+                check_in(store, rank, world, phase)               # host side, names the ranks that never arrived
+            try:
+                dist.barrier()
+            except Exception as exc:                              # a peer died between its check-in and the barrier
+                die(rank, f"barrier '{phase or 'end of timed region'}' failed", exc)
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
-    fence()
+    fence("warm-up done")
+    # per-step HIP events on the launch stream beside the host clock (median of >= 5 event-timed calls): marks[i]
+    # is recorded before step i, marks[K] after the last one
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        marks[i].record()
         image = step()
+    marks[args.steps].record()
     fence()
     elapsed_own = time.perf_counter() - t0
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     elapsed = elapsed_own
     ranks = None
     if world > 1:
@@ -512,8 +581,8 @@ def main():
         e2.record()
         torch.cuda.synchronize()
         h2 = time.perf_counter()
-        mine = torch.tensor([elapsed_own / args.steps * 1e3, e0.elapsed_time(e1), (h2 - h1) * 1e3, float(rhi - rlo)],
-                            dtype=torch.float64, device=cdev)
+        mine = torch.tensor([elapsed_own / args.steps * 1e3, e0.elapsed_time(e1), (h2 - h1) * 1e3, float(rhi - rlo),
+                             statistics.median(step_ms)], dtype=torch.float64, device=cdev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         rows = [[float(v) for v in r.cpu()] for r in allr]
@@ -532,14 +601,19 @@ def main():
         ranks = {"step_ms": [r[0] for r in rows], "compute_ms": [r[1] for r in rows],
                  "allreduce_wait_ms": [r[2] for r in rows], "source_points": [int(r[3]) for r in rows],
                  "step_ms_max": max(r[0] for r in rows), "step_ms_min": min(r[0] for r in rows),
+                 "median_step_ms": [r[4] for r in rows],
+                 "compute_ms_max": max(r[1] for r in rows), "compute_ms_min": min(r[1] for r in rows),
+                 "allreduce_wait_ms_max": max(r[2] for r in rows), "allreduce_wait_ms_min": min(r[2] for r in rows),
                  "allreduce_bytes": int(part.numel() * 4),
                  "world": dist.get_world_size(), "backend": backend + (" (RCCL)" if backend == "nccl" else ""), "rccl_version": rccl,
                  "devices": idents, "distinct_devices": len(set(idents)) if not str(idents[0]).startswith("unavailable") else None,
-                 "note": "step_ms = each rank's own mean over the timed steps; compute_ms (HIP events) and "
+                 "note": "step_ms = each rank's own mean over the timed steps, median_step_ms = its median by HIP events; compute_ms (HIP events) and "
                          "allreduce_wait_ms (host clock from this rank's compute done to its all-reduce done: "
                          "collective + waiting for the slowest rank) from one extra instrumented step"}
         del part, sh_all
     ms_per_step = elapsed / args.steps * 1e3
+    # SURVEY 8d asks for the median of >= 5 event-timed calls; `value` stays the contract's mean over the barrier-bracketed region
+    median_ms = max(ranks["median_step_ms"]) if ranks is not None else statistics.median(step_ms)
     units = float(S) * pn * pn * planes                          # source-point*pixels per step, whole job
     value = units * args.steps / elapsed
 
@@ -603,6 +677,8 @@ def main():
 
     out = {"metric": "Abbe source-points x image-pixels per second", "value": value, "unit": "source-pt*px/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+           "median_ms_per_step": median_ms, "value_at_median": units / (median_ms * 1e-3) if median_ms > 0 else None,
+           "step_ms": step_ms,
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic",
            "config": {"workload": (f"BASELINE {args.workload}: " if args.workload.startswith("cfg") else f"{args.workload}: ") + w.desc
@@ -620,6 +696,13 @@ def main():
     if not args.shard and args.points == 0:
         pred = predicted_step(args.workload, world, planes * pn * pn * 4)
         if pred:
+            # the record explains itself whichever way it comes out: measured step over predicted step, and (N > 1) where the
+            # difference sits -- the slowest rank's compute against the prediction's compute share, the all-reduce wait against its price
+            pred["measured_over_predicted"] = ms_per_step / pred["predicted_step_ms"]
+            if ranks is not None:
+                pred["compute_ms_max_over_predicted_compute"] = ranks["compute_ms_max"] / max(1e-9, pred["predicted_step_ms"] - pred["predicted_allreduce_ms"])
+                pred["allreduce_wait_ms_min_over_predicted_allreduce"] = (ranks["allreduce_wait_ms_min"] / pred["predicted_allreduce_ms"]
+                                                                          if pred["predicted_allreduce_ms"] > 0 else None)
             out["prediction"] = pred
 
     # ---- CPU baseline leg: the oracle's op-chain port of the reference loop, rank 0, N = 1 only.  GPU half now (the workload is
@@ -634,8 +717,8 @@ def main():
         torch.cuda.empty_cache()
         extras = []
         for name, kw in (("cfg1", dict(steps=5, profile_points=1 << 30)), ("cfg2", dict(steps=2, profile_points=4800)),
-                         ("cfg4", dict(shard=(0, 8), steps=1, warm_points=600, profile_points=2400)),
-                         ("cfg5", dict(steps=1, warm_points=240, profile_points=240)),
+                         ("cfg4", dict(shard=(0, 8), steps=2, warm_points=600, profile_points=2400)),
+                         ("cfg5", dict(steps=2 if args.steps >= 5 else 1, warm_points=240, profile_points=240)),
                          ("odd2000", dict(steps=1, warm_points=480, profile_points=480))):
             try:
                 extras.append(extra_workload(torch, nat, dev, name, cpu=not args.no_cpu_baseline, **kw))

@@ -73,6 +73,18 @@ int litho_source_compact(const int64_t *bitmap, int pn, int32_t *shifts, int64_t
 int litho_pupil(uint16_t *coeffs_f16_host, int J, int pn, double NA, double wavelength, int flags,
                 uint16_t *wavefront, void *pupil, void *stream);
 
+/* ---- Through-focus pupil stack (the pupil export "batched over P defocus planes").  The reference has no
+ * stack call: its counterpart is a Python loop `ab = aberrations.clone(); ab[4] = d_p; Pupil(pn, wavelength, NA, ab)
+ * .generatePupilFunction()` per plane, i.e. pupil.py:88-100 + 102-111 run once per defocus value with the rescale of
+ * pupil.py:91-92 applied to each d_p.  Here: ONE launch per 64 planes writes wavefront fp16 [planes,pn,pn] and / or pupil
+ * complex64 [planes,pn,pn] in place; the sigma grid, r, theta and the J - 1 other Zernike terms are evaluated once per pixel,
+ * the fp16 running sum is re-run per plane in the reference's order.  Bit-identical to `planes` litho_pupil calls.
+ * coeffs_f16_host: J >= 5 fp16 bit patterns (coefficient 4 is ignored; J < 5: LITHO_E_INDEX, as `ab[4] = d` raises);
+ * defocus_f16_host: `planes` fp16 bit patterns, the values of coefficient 4 BEFORE the rescale.  Nothing is written back
+ * (the loop above works on clones).  Asynchronous for J <= 32; longer vectors run plane by plane through litho_pupil. */
+int litho_pupil_stack(const uint16_t *coeffs_f16_host, int J, const uint16_t *defocus_f16_host, int planes, int pn,
+                      double NA, double wavelength, uint16_t *wavefront, void *pupil, void *stream);
+
 /* ---- generatePhi (pupil.py:102-111): pupil = exp(1j*2*pi*WE) for a complex64 wavefront
  * error WE [pn,pn], zero where the fp16 radius exceeds 1. */
 int litho_pupil_phase(const void *wavefront_c64, int pn, void *pupil, void *stream);

@@ -25,6 +25,7 @@ _SIGNATURES = {
                                     c_void_p, c_void_p]),
     "litho_source_compact": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, POINTER(c_int64), c_void_p]),
     "litho_pupil": (c_int, [c_void_p, c_int, c_int, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p]),
+    "litho_pupil_stack": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p]),
     "litho_pupil_phase": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "litho_abbe_workspace_bytes": (c_int, [c_int, c_int, POINTER(c_size_t)]),
     "litho_abbe_accumulate": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p,

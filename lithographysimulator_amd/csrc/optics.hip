@@ -193,6 +193,60 @@ __global__ void k_pupil_packed(const ZTermPack pack, int J, int pn, float fs, fl
     pupil_body(pack.t, J, pn, fs, fst, twopi_f, wavefront, pupil);
 }
 
+// Through-focus stack ("optionally batched over P defocus planes"): the planes of a stack differ in
+// coefficient 4 only, so the sigma grid, r, theta and every Zernike term but the defocus one are evaluated ONCE per pixel;
+// per plane remain the defocus term's last two products (its radial polynomial and cos(0 * theta) are shared), the
+// fp16-rounded running sum W = h(W + Z_j) in the reference's order j = 0 .. J-1 (pupil.py:95-99 -- the chain is re-run per
+// plane because every partial sum after j = 4 depends on the plane) and the phase.  Same operations, same roundings as
+// pupil_body: bit-identical to `planes` single-plane launches.
+static constexpr int STACK_PLANES = 64;              // planes per launch: their defocus factors ride in the kernel arguments
+struct StackPlanes {
+    float cN4[STACK_PLANES];                         // h(c4_p * fp32(N_20)), c4_p after the two-rounding rescale (pupil.py:91-92)
+};
+
+__global__ void k_pupil_stack(const ZTermPack pack, int J, const StackPlanes sp, int planes, int pn, float fs, float fst,
+                              float twopi_f, uint16_t* __restrict__ wavefront, float2* __restrict__ pupil)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = blockIdx.y;
+    if (col >= pn) return;
+    const float x = sigma_axis(col, pn, fs, fst);
+    const float y = sigma_axis(row, pn, fs, fst);
+    const float r = radius16(x, y);
+    const bool inside = r <= 1.f;
+    const float theta = h16((float)atan2((double)y, (double)x));
+    float Z[PACK_TERMS];                             // Z_j of the shared terms; slot 4 is not used
+    float R4 = 0.f, trig4 = 0.f;
+    for (int j = 0; j < J; ++j) {
+        const ZTerm t = pack.t[j];
+        float acc = 0.f;
+        for (int k = 0; k < t.nk; ++k) acc = acc + h16(t.coef[k] * h16(pow_int_rn(r, t.n - 2 * k)));
+        const float R = h16(acc);
+        const float arg = h16((float)t.m * theta);
+        const float trig = h16((float)(t.m >= 0 ? cos((double)arg) : sin((double)arg)));
+        if (j == 4) { R4 = R; trig4 = trig; }
+        float z = h16(h16(t.cN * R) * trig);
+        if (!inside) z = 0.f;
+        Z[j] = z;
+    }
+    const size_t idx = (size_t)row * pn + col, plane = (size_t)pn * pn;
+    for (int p = 0; p < planes; ++p) {
+        float z4 = h16(h16(sp.cN4[p] * R4) * trig4);
+        if (!inside) z4 = 0.f;
+        float W = 0.f;
+        for (int j = 0; j < J; ++j) W = h16(W + (j == 4 ? z4 : Z[j]));
+        if (wavefront) wavefront[p * plane + idx] = __half_as_ushort(__float2half_rn(W));
+        if (pupil) {
+            float2 phi = make_float2(0.f, 0.f);
+            if (inside) {
+                const float ang = twopi_f * W;
+                phi = make_float2((float)cos((double)ang), (float)sin((double)ang));
+            }
+            pupil[p * plane + idx] = phi;
+        }
+    }
+}
+
 // generatePhi (pupil.py:102-111) for an arbitrary complex64 WE = a + i b:
 // exp(i 2 pi WE) = exp(-2 pi b) (cos 2 pi a + i sin 2 pi a), with 2 pi held in fp32.
 __global__ void k_pupil_phase(const float2* __restrict__ we, int pn, float fs, float fst, float twopi_f,
@@ -374,23 +428,12 @@ int litho_source_compact(const int64_t* bitmap, int pn, int32_t* shifts, int64_t
     return total > capacity ? LITHO_E_ARG : LITHO_OK;
 }
 
-int litho_pupil(uint16_t* coeffs_f16_host, int J, int pn, double NA, double wavelength, int flags,
-                uint16_t* wavefront, void* pupil, void* stream)
+// c[j] (fp32 values of the fp16 coefficients, coefficient 4 already rescaled) -> the per-term constants of pupil.py:46-77
+static int build_terms(const std::vector<float>& c, std::vector<litho::ZTerm>& terms)
 {
     using namespace litho;
-    if (!coeffs_f16_host || J < 1 || pn < 1) return LITHO_E_ARG;
-    if (!wavefront && !pupil) return LITHO_E_ARG;
-    const bool rescale = !(flags & 1);
-    if (rescale && J == 4) return LITHO_E_INDEX;                         // pupil.py:91-92 indexes [4] (Q3)
-    hipStream_t st = (hipStream_t)stream;
-    std::vector<float> c(J);
-    for (int j = 0; j < J; ++j) c[j] = __half2float(__ushort_as_half(coeffs_f16_host[j]));
-    if (rescale && J >= 4) {                                             // defocus rescale, two fp16 roundings
-        const float t = h16_host(c[4] * (float)(NA * NA));
-        c[4] = h16_host(t / (float)(4.0 * wavelength));
-        coeffs_f16_host[4] = __half_as_ushort(__float2half_rn(c[4]));    // the reference mutates its argument (Q2)
-    }
-    std::vector<ZTerm> terms(J);
+    const int J = (int)c.size();
+    terms.resize(J);
     for (int j = 0; j < J; ++j) {
         ZTerm& t = terms[j];
         t.n = osa_n(j);                                                  // pupil.py:84-85
@@ -407,6 +450,34 @@ int litho_pupil(uint16_t* coeffs_f16_host, int J, int pn, double NA, double wave
         const double Nmn = std::sqrt((2.0 * t.n + 1.0) / (1.0 + (t.m == 0 ? 1.0 : 0.0)));   // pupil.py:68
         t.cN = h16_host(c[j] * (float)(t.m >= 0 ? Nmn : -Nmn));          // pupil.py:71/73
     }
+    return LITHO_OK;
+}
+
+// pupil.py:91-92: aberrations[4] = aberrations[4] * NA**2 / (4 * wavelength) on an fp16 tensor -- two fp16 roundings
+static float rescale_defocus(float c4, double NA, double wavelength)
+{
+    const float t = litho::h16_host(c4 * (float)(NA * NA));
+    return litho::h16_host(t / (float)(4.0 * wavelength));
+}
+
+int litho_pupil(uint16_t* coeffs_f16_host, int J, int pn, double NA, double wavelength, int flags,
+                uint16_t* wavefront, void* pupil, void* stream)
+{
+    using namespace litho;
+    if (!coeffs_f16_host || J < 1 || pn < 1) return LITHO_E_ARG;
+    if (!wavefront && !pupil) return LITHO_E_ARG;
+    const bool rescale = !(flags & 1);
+    if (rescale && J == 4) return LITHO_E_INDEX;                         // pupil.py:91-92 indexes [4] (Q3)
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<float> c(J);
+    for (int j = 0; j < J; ++j) c[j] = __half2float(__ushort_as_half(coeffs_f16_host[j]));
+    if (rescale && J >= 4) {                                             // defocus rescale, two fp16 roundings
+        c[4] = rescale_defocus(c[4], NA, wavelength);
+        coeffs_f16_host[4] = __half_as_ushort(__float2half_rn(c[4]));    // the reference mutates its argument (Q2)
+    }
+    std::vector<ZTerm> terms;
+    const int rc = build_terms(c, terms);
+    if (rc) return rc;
     if (J <= PACK_TERMS) {                                               // asynchronous: terms ride in the kernarg segment
         ZTermPack pack;
         memset(&pack, 0, sizeof(pack));
@@ -424,6 +495,49 @@ int litho_pupil(uint16_t* coeffs_f16_host, int J, int pn, double NA, double wave
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));       // `terms` is pageable host memory; keep it alive until copied
     HIP_TRY(hipFreeAsync(dterms, st));
+    return LITHO_OK;
+}
+
+int litho_pupil_stack(const uint16_t* coeffs_f16_host, int J, const uint16_t* defocus_f16_host, int planes, int pn, double NA,
+                      double wavelength, uint16_t* wavefront, void* pupil, void* stream)
+{
+    using namespace litho;
+    if (!coeffs_f16_host || !defocus_f16_host || J < 1 || planes < 1 || pn < 1) return LITHO_E_ARG;
+    if (!wavefront && !pupil) return LITHO_E_ARG;
+    if (J < 5) return LITHO_E_INDEX;                                     // `ab[4] = d` on a shorter vector: IndexError
+    hipStream_t st = (hipStream_t)stream;
+    const size_t plane = (size_t)pn * pn;
+    if (J > PACK_TERMS) {                                                // long vectors: plane by plane through the staged table
+        std::vector<uint16_t> cj(coeffs_f16_host, coeffs_f16_host + J);
+        for (int p = 0; p < planes; ++p) {
+            cj[4] = defocus_f16_host[p];
+            const int rc = litho_pupil(cj.data(), J, pn, NA, wavelength, 0, wavefront ? wavefront + p * plane : nullptr,
+                                       pupil ? (void*)((float2*)pupil + p * plane) : nullptr, stream);
+            if (rc) return rc;
+        }
+        return LITHO_OK;
+    }
+    std::vector<float> c(J);
+    for (int j = 0; j < J; ++j) c[j] = __half2float(__ushort_as_half(coeffs_f16_host[j]));
+    c[4] = 0.f;                                                          // replaced per plane
+    std::vector<ZTerm> terms;
+    const int rc = build_terms(c, terms);
+    if (rc) return rc;
+    ZTermPack pack;
+    memset(&pack, 0, sizeof(pack));
+    for (int j = 0; j < J; ++j) pack.t[j] = terms[j];
+    const float N20 = (float)std::sqrt((2.0 * 2 + 1.0) / 2.0);           // term 4 = (m, n) = (0, 2): +N_mn, pupil.py:68/71
+    for (int p0 = 0; p0 < planes; p0 += STACK_PLANES) {
+        const int np = planes - p0 < STACK_PLANES ? planes - p0 : STACK_PLANES;
+        StackPlanes sp;
+        memset(&sp, 0, sizeof(sp));
+        for (int p = 0; p < np; ++p)
+            sp.cN4[p] = h16_host(rescale_defocus(__half2float(__ushort_as_half(defocus_f16_host[p0 + p])), NA, wavelength) * N20);
+        hipLaunchKernelGGL(k_pupil_stack, dim3((pn + 255) / 256, pn), dim3(256), 0, st, pack, J, sp, np, pn, -2.0f,
+                           (float)(4.0 / pn), (float)(2.0 * M_PI), wavefront ? wavefront + p0 * plane : nullptr,
+                           pupil ? (float2*)pupil + p0 * plane : nullptr);
+        HIP_TRY(hipGetLastError());
+    }
     return LITHO_OK;
 }
 

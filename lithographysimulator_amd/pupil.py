@@ -97,12 +97,27 @@ class Pupil:
         return generateWavefrontError(self.aberrations, self.pixelNumber, self.NA, self.wavelength, self.device)
 
 
-def throughFocusPupils(pixelNumber, wavelength, NA, aberrations, defocus_values, device):
-    """Stack of pupil functions that differ only in coefficient 4: the
-    reference's counterpart is a Python loop over Pupil(...).generatePupilFunction()."""
-    planes = []
-    for d in defocus_values:
-        ab = aberrations.clone()
-        ab[4] = d
-        planes.append(Pupil(pixelNumber, wavelength, NA, ab, device).generatePupilFunction())
-    return torch.stack(planes)
+def throughFocusPupils(pixelNumber, wavelength, NA, aberrations, defocus_values, device, wavefront=False):
+    """Stack of pupil functions that differ only in coefficient 4, complex64 [planes,pn,pn], written
+    in place by ONE litho_pupil_stack launch per 64 planes.  The reference has no stack call; its counterpart is the loop
+    `ab = aberrations.clone(); ab[4] = d; Pupil(pn, wavelength, NA, ab, device).generatePupilFunction()` per defocus
+    value (pupil.py:88-111), which this reproduces bit for bit (the caller's `aberrations` is left alone, as the clones
+    leave it).  wavefront=True: returns (W fp16 [planes,pn,pn], phi) -- every plane's fp16 wavefront error as well."""
+    dev = nat.require_gpu(device)
+    pn = int(pixelNumber)
+    J = len(aberrations)
+    if J < 5:
+        raise IndexError(f"index 4 is out of bounds for dimension 0 with size {J}")
+    planes = len(defocus_values)
+    if planes < 1:
+        raise ValueError("defocus_values must hold at least one plane")
+    as_bits = lambda t: np.ascontiguousarray(t.detach().to(torch.float16).cpu().contiguous().view(torch.int16).numpy().astype(np.uint16))
+    coeffs = as_bits(aberrations)
+    defocus = as_bits(torch.as_tensor(defocus_values, dtype=torch.float64).to(torch.float16))   # `ab[4] = d` rounds d to fp16
+    W = torch.empty((planes, pn, pn), dtype=torch.float16, device=dev) if wavefront else None
+    phi = torch.empty((planes, pn, pn), dtype=torch.complex64, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(nat.lib().litho_pupil_stack(coeffs.ctypes.data, J, defocus.ctypes.data, planes, pn, float(NA), float(wavelength),
+                                              nat.ptr(W) if wavefront else None, nat.ptr(phi), nat.stream_ptr(dev)),
+                  "litho_pupil_stack")
+    return (W, phi) if wavefront else phi

@@ -31,7 +31,7 @@ def declared_symbols():
 def test_header_declares_the_expected_entry_points():
     names = declared_symbols()
     for must in ("litho_abbe_accumulate", "litho_abbe_field", "litho_source_bitmap", "litho_source_compact",
-                 "litho_pupil", "litho_postprocess", "litho_mask_spectrum", "litho_abbe_workspace_bytes",
+                 "litho_pupil", "litho_pupil_stack", "litho_postprocess", "litho_mask_spectrum", "litho_abbe_workspace_bytes",
                  "litho_epsilon_n"):
         assert must in names
 
@@ -128,6 +128,18 @@ def test_pupil_length_4_is_an_index_error_before_any_gpu_work(nat):
     # J == 4 is rejected on the host (pupil.py:91-92 indexes [4]); no device is touched
     coeffs = (ctypes.c_uint16 * 4)(0, 0, 0, 0x3C00)
     assert nat.lib().litho_pupil(coeffs, 4, 64, 0.7, 193.0, 0, None, ctypes.c_void_p(8), None) == nat.E_INDEX
+
+
+def test_pupil_stack_argument_errors_before_any_gpu_work(nat):
+    # litho_pupil_stack: `ab[4] = d` on a vector shorter than 5 is the reference loop's IndexError; nulls / empty stacks are E_ARG
+    lib = nat.lib()
+    c4, c5, d = (ctypes.c_uint16 * 4)(), (ctypes.c_uint16 * 5)(), (ctypes.c_uint16 * 2)(0x5640, 0xD640)
+    out = ctypes.c_void_p(8)
+    assert lib.litho_pupil_stack(c4, 4, d, 2, 64, 0.7, 193.0, None, out, None) == nat.E_INDEX
+    assert lib.litho_pupil_stack(c5, 5, d, 0, 64, 0.7, 193.0, None, out, None) == nat.E_ARG
+    assert lib.litho_pupil_stack(c5, 5, None, 2, 64, 0.7, 193.0, None, out, None) == nat.E_ARG
+    assert lib.litho_pupil_stack(None, 5, d, 2, 64, 0.7, 193.0, None, out, None) == nat.E_ARG
+    assert lib.litho_pupil_stack(c5, 5, d, 2, 64, 0.7, 193.0, None, None, None) == nat.E_ARG
 
 
 def test_diag_switches_do_not_compile_into_the_product():

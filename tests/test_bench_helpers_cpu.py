@@ -70,3 +70,47 @@ def test_traffic_entries_are_dropped_on_kernel_or_geometry_mismatch():
     b.attach_traffic("cfg4", k, dict(geo))
     assert "traffic" in k["xpass"] and "traffic" not in k["ypass"] and "k_ypass_coop<12, 4>" in k["ypass"]["traffic_stale"]
     assert b.attach_traffic("no-such-workload", kern(), dict(geo)) is None or True
+
+
+def test_gpus_flag_and_world_size(tmp_path):
+    """--gpus that contradicts the launcher's WORLD_SIZE is refused before any GPU work; WITHOUT --gpus the launcher's
+    WORLD_SIZE is adopted (`torchrun --nproc-per-node N bench.py`, round-5 advice: the default of 1 used to refuse it)."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cfg1"], capture_output=True, text=True,
+                         timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr
+    b = _bench()
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        assert b.parse_args().gpus is None                       # not given: main() takes WORLD_SIZE (or 1)
+        sys.argv = ["bench.py", "--gpus", "8"]
+        assert b.parse_args().gpus == 8
+    finally:
+        sys.argv = argv
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "if args.gpus is not None and args.gpus != world:" in src and "args.gpus = world" in src
+
+
+def test_check_in_names_the_missing_rank_and_exits_non_zero():
+    """First-contact insurance: a peer that never arrives ends this rank in seconds with the peer NAMED and a non-zero code
+    (here: world 2, only rank 0 exists, 1 s timeout) -- and a complete phase returns at once."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    code = (
+        "import importlib.util, sys, datetime\n"
+        f"spec = importlib.util.spec_from_file_location('b', r'{os.path.join(ROOT, 'bench.py')}')\n"
+        "b = importlib.util.module_from_spec(spec); sys.argv = ['bench.py']; spec.loader.exec_module(b)\n"
+        "import torch.distributed as dist\n"
+        f"store = dist.TCPStore('127.0.0.1', {port}, 1, True, timeout=datetime.timedelta(seconds=30))\n"
+        "b.check_in(store, 0, 1, 'alone', timeout_s=1)\n"
+        "print('phase one complete', flush=True)\n"
+        "b.check_in(store, 0, 2, 'pair', timeout_s=1)\n"
+        "print('not reached', flush=True)\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 3, (out.returncode, out.stderr[-500:])
+    assert "phase one complete" in out.stdout and "not reached" not in out.stdout
+    assert "rank 0" in out.stderr and "rank(s) [1] of 2 did not arrive" in out.stderr and "'pair'" in out.stderr

@@ -115,6 +115,55 @@ def test_pupil_large(golden, L, dev, pn):
         assert float((sub - ref).abs().max()) < TOL_PHI           # every sample (0 outliers observed)
 
 
+@pytest.mark.parametrize("pn", [64, 256])
+def test_pupil_stack_vs_golden(golden, L, dev, pn):
+    """litho_pupil_stack: the planes of ONE launch against the reference-made single pupils of g2 -- the
+    defocus-only vectors [0,0,0,0,d] as three planes of one stack, and the demo vector as a one-plane stack: fp16 W
+    bit-exact, phi on every pixel."""
+    g = golden("g2_pupils.npz")
+    W, phi = L.throughFocusPupils(pn, WL, NA, f16([0, 0, 0, 0, 7]), [100.0, -200.0, 30.0], dev, wavefront=True)
+    assert tuple(phi.shape) == (3, pn, pn) and phi.dtype == torch.complex64 and W.dtype == torch.float16
+    for p, name in enumerate(("defocus_p100", "defocus_m200", "defocus_p30")):
+        Wref = torch.from_numpy(g[f"W_{name}_{pn}"]).view(torch.float16)
+        assert int((W[p].cpu() != Wref).sum()) == 0, name
+        ref = torch.from_numpy(g[f"phi_{name}_{pn}"])
+        assert torch.equal(phi[p].cpu() != 0, ref != 0) and float((phi[p].cpu() - ref).abs().max()) < TOL_PHI
+    ab = f16(PUPIL_CASES["demo"])
+    before = ab.clone()
+    W, phi = L.throughFocusPupils(pn, WL, NA, ab, [float(PUPIL_CASES["demo"][4])], dev, wavefront=True)
+    assert torch.equal(ab, before)                               # the reference's loop works on clones: caller's vector untouched
+    assert int((W[0].cpu() != torch.from_numpy(g[f"W_demo_{pn}"]).view(torch.float16)).sum()) == 0
+    assert float((phi[0].cpu() - torch.from_numpy(g[f"phi_demo_{pn}"])).abs().max()) < TOL_PHI
+
+
+@pytest.mark.parametrize("pn,J,planes", [(64, 5, 1), (64, 10, 70), (256, 15, 9), (64, 40, 3), (2048, 10, 32)])
+def test_pupil_stack_equals_single_plane_launches(L, dev, pn, J, planes):
+    """One stacked launch (per 64 planes) = `planes` litho_pupil calls, bit for bit in W AND phi: every term count (5 = the
+    defocus term is the last, 15, 40 = beyond the 32 terms that travel in the kernel arguments), more planes than one launch
+    holds (70), and config 5 at its size (2048^2 x 32 planes, defocus -310 .. 310 nm, demo vector)."""
+    gen = torch.Generator().manual_seed(100 * J + planes)
+    ab = PUPIL_CASES["demo"] if J == 10 else [0.0, 0.0] + [float(v) for v in (torch.rand(J - 2, generator=gen) * 0.04 - 0.02)]
+    defocus = [-310.0 + 20.0 * k for k in range(32)] if planes == 32 else [float(v) for v in (torch.rand(planes, generator=gen) * 600 - 300)]
+    W, phi = L.throughFocusPupils(pn, WL, NA, f16(ab), defocus, dev, wavefront=True)
+    assert tuple(W.shape) == tuple(phi.shape) == (planes, pn, pn)
+    for p in (range(planes) if pn < 2048 else (0, 13, 31)):
+        one = f16(ab).clone()
+        one[4] = defocus[p]
+        W1 = L.Pupil(pn, WL, NA, one.clone(), dev).generateWavefrontError().real.to(torch.float16)
+        phi1 = L.Pupil(pn, WL, NA, one.clone(), dev).generatePupilFunction()
+        assert torch.equal(W[p].view(torch.int16), W1.view(torch.int16)), p
+        assert torch.equal(torch.view_as_real(phi[p]), torch.view_as_real(phi1)), p
+    if pn == 2048:                                               # every plane of config 5's stack has the ideal pupil's support
+        assert [int(v) for v in (phi != 0).flatten(1).sum(1).cpu()] == [int((phi[0] != 0).sum())] * planes
+
+
+def test_pupil_stack_short_vector_raises(L, dev):
+    with pytest.raises(IndexError):
+        L.throughFocusPupils(64, WL, NA, f16([0, 0, 0, 1]), [10.0], dev)
+    with pytest.raises(ValueError):
+        L.throughFocusPupils(64, WL, NA, f16([0, 0, 0, 0, 1]), [], dev)
+
+
 def test_generate_phi_and_z(L, dev):
     from oracle import abbe_oracle as O
     W = O.wavefront_error(f16(PUPIL_CASES["demo"]), 64, NA, WL)

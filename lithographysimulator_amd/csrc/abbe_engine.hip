@@ -425,18 +425,27 @@ const SizeOps* size_ops(int log2n)
 // A few dozen ints of PINNED host memory per calling thread for the read-backs (plan words, the split's ten words).  Into
 // pageable memory (a stack array) the runtime stages the 56 bytes through a blit kernel and a bounce buffer: 44 us on the
 // device timeline of a config-1 image (rocprofv3: __amd_rocclr_copyBuffer), a twelfth of the whole image; nullptr if the
-// allocation fails (then the stack array is used as before).  Never freed: a thread's buffer lives as long as the process.
+// allocation fails (then the stack array is used as before).  One buffer per calling thread, freed when the thread exits.
+struct PinnedWords {
+    int* p = nullptr;
+    bool tried = false;
+    ~PinnedWords() { if (p) (void)hipHostFree(p); }          // thread exit: a host application's short-lived worker threads do not leak
+};
 static int* pinned_words()
 {
-    static thread_local int* p = nullptr;
-    static thread_local bool tried = false;
-    if (!tried) {
-        tried = true;
+    static thread_local PinnedWords pw;
+    if (!pw.tried) {
+        pw.tried = true;
+        // the first call of a thread may come while that thread captures a stream: an allocation is not a capturable
+        // operation, so it is made under the relaxed capture mode (and does not invalidate the capture)
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+        const bool swapped = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
         void* q = nullptr;
-        if (hipHostMalloc(&q, 64 * sizeof(int), hipHostMallocPortable) == hipSuccess) p = (int*)q;
+        if (hipHostMalloc(&q, 64 * sizeof(int), hipHostMallocPortable) == hipSuccess) pw.p = (int*)q;
         else (void)hipGetLastError();
+        if (swapped) (void)hipThreadExchangeStreamCaptureMode(&mode);
     }
-    return p;
+    return pw.p;
 }
 // n ints from the device to `host` (one small synchronising copy)
 static int read_words(const int* dev, int* host, int n, hipStream_t st)

@@ -474,6 +474,9 @@ struct RunPlan {
     EdgeGeom eg;
     const AbbePlan& run() const { return coarse ? coarse_plan : direct; }
 };
+// T bytes the once-per-plane reconstruction of the coarse-grid path needs (both of its transform pairs write one pn x pn item
+// of 4-column tiles into the head of T, after the source-point loop is done with it)
+static inline size_t reconstruct_t_bytes(int pn) { return general_item_bytes(pn); }
 // `have_ops_c`: whether kernels of size pn exist (size_ops(ilog2(pn)) != nullptr: 16 <= pn <= 16384, always true where the
 // coarse grid is eligible).  S = source points of this run.
 static inline int plan_run(RunPlan& rp, size_t t_bytes, const Knobs& kn, const int pl[PLAN_WORDS], int pn, int N, int planes,
@@ -499,14 +502,15 @@ static inline int plan_run(RunPlan& rp, size_t t_bytes, const Knobs& kn, const i
         eg.lo[1] = pl[12] >= pl[11] ? pl[11] : 0; eg.len[1] = pl[12] >= pl[11] ? pl[12] - pl[11] + 1 : 0;
         coarse = have_ops_c && eg.len[0] <= EDGE_MAX && eg.len[1] <= EDGE_MAX &&
                  plan_abbe(rp.coarse_plan, t_bytes, kn, pl, pn, pn, planes, cus) == LITHO_OK && rp.coarse_plan.variant == 0 && rp.coarse_plan.wave_y &&
-                 rp.coarse_plan.PC <= COARSE_PLANES;
+                 rp.coarse_plan.PC <= COARSE_PLANES &&
+                 // the reconstruction writes one general-mode item (2x a pruned coarse item) into the head of T: a T region cut
+                 // short by the two lists of a split source list (only SPLIT_T_ROOM is guaranteed) must still hold it, or the
+                 // reconstruction would run into the wrapping part's list (round-5 advice: only the dry-run TEST compared them)
+                 t_bytes >= reconstruct_t_bytes(pn);
     }
     rp.coarse = coarse;
     return LITHO_OK;
 }
-// T bytes the once-per-plane reconstruction of the coarse-grid path needs (both of its transform pairs write one pn x pn item
-// of 4-column tiles into the head of T, after the source-point loop is done with it)
-static inline size_t reconstruct_t_bytes(int pn) { return general_item_bytes(pn); }
 
 // ----------------------------------------------------------------------------------
 // Call level (abbe_accumulate): the grid the problem runs at, and where the two lists of a split source list go.
@@ -588,15 +592,23 @@ static inline void embed_plan_words(const int pl[PLAN_WORDS], int pn, int pe, in
 // 5) the outcome of the source-list split, so that a planned call with a partly wrapping (shifted) source keeps the fast path
 // for its non-wrapping points: it re-runs the three small split kernels (deterministic, no read-back) and plans the two parts
 // from the recorded counts and extents.  Sixteen words hold all that only packed: coordinates and shifts are < 2^15 in
-// magnitude (pn <= 16384), the "none seen" sentinels INT_MAX / INT_MIN travel as 32767 / -32768.
+// magnitude (pn <= 16384; shift extents beyond +-16384 are clamped there: they wrap on every grid), the "none seen" sentinels
+// INT_MAX / INT_MIN travel as 32767 / -32768.
 //   [0] box rows lo | hi << 16   [1] box columns   [2] dy min | max   [3] dx min | max   [4] source-point count
 //   [5] edge rows ([9],[10])     [6] edge columns ([11],[12])        [7] corner flag | run size << 8
 //   [8] RECORD_TAG | split flag  [9] non-wrapping count              [10],[11] its dy, dx extents   [12],[13] the wrapping part's
 // ----------------------------------------------------------------------------------
 static constexpr int32_t RECORD_TAG = 0x4C500500;            // "LP", format 5
+// The C ABI takes any int32 shift (the general path reduces it modulo pn); extents beyond +-16384 = the largest pn already mean
+// "wraps" on every grid, so they are CLAMPED there -- the no-wrap decision of a planned call is then the planning call's, and no
+// real value can collide with a sentinel (round-5 advice: a truncated extent could judge no-wrap differently on reuse, and an
+// extent of exactly 32767 / -32768 came back as INT_MAX / INT_MIN, whose sum in list_nowrap overflows).
+static constexpr int RECORD_EXTENT_CLAMP = 16384;
 static inline int32_t pack16(int lo, int hi)
 {
-    auto c = [](int v) { return v == INT_MAX ? 32767 : v == INT_MIN ? -32768 : v; };
+    auto c = [](int v) {
+        return v == INT_MAX ? 32767 : v == INT_MIN ? -32768 : v > RECORD_EXTENT_CLAMP ? RECORD_EXTENT_CLAMP : v < -RECORD_EXTENT_CLAMP ? -RECORD_EXTENT_CLAMP : v;
+    };
     return (int32_t)(((uint32_t)(uint16_t)(int16_t)c(lo)) | ((uint32_t)(uint16_t)(int16_t)c(hi) << 16));
 }
 static inline void unpack16(int32_t w, int& lo, int& hi)

@@ -277,6 +277,21 @@ int main() {
         for (int i = 0; i < 14; ++i) if (pl[i] != (i == 13 ? (cases[c][13] ? 1 : 0) : cases[c][i])) ++bad;
         if (split) { if (sw[0] != sws[c][0] || sw[1] != cases[c][8] - sws[c][0]) ++bad; for (int i = 2; i < 10; ++i) if (sw[i] != sws[c][i]) ++bad; }
     }
+    // shifts beyond int16 (the ABI takes any int32; the general path reduces them modulo pn): clamped to +-16384, never mistaken for
+    // a sentinel, and the no-wrap decision of the reloaded words equals that of the original ones on every grid size
+    const int huge[][4] = {{-40000, 50000, -32768, 32767}, {32767, 32767, -32768, -32768}, {-16385, 16385, 100000, 2000000000}, {-3, 5, -32769, 7}};
+    for (auto& h : huge) for (int pn : {64, 2048, 16384}) {
+        int pl0[14] = {pn / 4, 3 * pn / 4, pn / 4, 3 * pn / 4, h[0], h[1], h[2], h[3], 77, INT_MAX, INT_MIN, INT_MAX, INT_MIN, 0};
+        int32_t w[16]; int pl[14], sw[10];
+        const int sw0[10] = {70, 7, -3, 5, -2, 2, h[0], h[1], h[2], h[3]};
+        record_store(w, pl0, pn, sw0);
+        if (!record_load(w, pl, sw)) ++bad;
+        for (int i = 4; i < 8; ++i) {
+            const int want = pl0[i] > 16384 ? 16384 : pl0[i] < -16384 ? -16384 : pl0[i];
+            if (pl[i] != want || sw[i + 2] != want) ++bad;
+        }
+        if (list_nowrap(pl, pn) != list_nowrap(pl0, pn) || list_nowrap(pl, pn)) ++bad;      // all of these wrap, before and after
+    }
     int32_t z[16] = {0}; if (record_is_ours(z)) ++bad;
     printf("%%d\n", bad);
     return bad;

@@ -126,37 +126,160 @@ __global__ void k_shift_extents(const int* __restrict__ shifts, long long S, con
     }
 }
 
+// ----------------------------------------------------------------------------------
+// The same plan words in ONE gathering launch + one single-block finish (round 6): k_plan_init + k_pupil_box + k_shift_extents
+// + the runtime's copy kernel were four dependent small launches in front of the one host wait of an image -- at 256^2 a tenth
+// of the image.  Every block writes its partial extrema to its own 16-int slot (no atomics, so nothing to initialise); the
+// finish block folds them, stores the words on the device AND into the calling thread's pinned, device-mapped host buffer, and
+// raises a sequence flag there, which the host polls (no copy kernel, no interrupt-driven wake-up for a wait of microseconds).
+//   box blocks  [0, nb_box): BOX_ROWS_PER_BLOCK rows of one plane -> slot {rmin, rmax, cmin, cmax, e9, e10, e11, e12, corner}
+//   extent blocks [nb_box, nb_box + nb_ext): grid-stride over the shift list -> slot {dymin, dymax, dxmin, dxmax}
+// ----------------------------------------------------------------------------------
+static constexpr int PLAN_PART = 16;
+__global__ __launch_bounds__(256) void k_plan_gather(const float2* __restrict__ P, int pn, int e_lo, int e_hi, int nb_box_x, int nb_box,
+                                                     const int* __restrict__ shifts, long long S, const int* __restrict__ count_dev,
+                                                     int nb_ext, int* __restrict__ part)
+{
+    __shared__ int red[4][9];
+    const int b = blockIdx.x, wv = threadIdx.x >> 6;
+    int v[9] = {INT_MAX, INT_MIN, INT_MAX, INT_MIN, INT_MAX, INT_MIN, INT_MAX, INT_MIN, 0};   // even: minima, odd: maxima, [8]: or
+    if (b < nb_box) {
+        const int row0 = (b % nb_box_x) * BOX_ROWS_PER_BLOCK;
+        const float2* plane = P + (size_t)(b / nb_box_x) * pn * pn;
+        for (int row = row0; row < min(pn, row0 + BOX_ROWS_PER_BLOCK); ++row) {
+            const float2* r = plane + (size_t)row * pn;
+            for (int j = threadIdx.x; j < pn; j += blockDim.x) {
+                const float2 s = r[j];
+                if (s.x != 0.f || s.y != 0.f) {
+                    v[0] = min(v[0], row); v[1] = max(v[1], row); v[2] = min(v[2], j); v[3] = max(v[3], j);
+                    const bool ecol = (j == e_hi || j == e_lo), erow = (row == e_hi || row == e_lo);
+                    if (ecol) { v[4] = min(v[4], row); v[5] = max(v[5], row); }
+                    if (erow) { v[6] = min(v[6], j); v[7] = max(v[7], j); }
+                    if (ecol && erow) v[8] = 1;
+                }
+            }
+        }
+    } else {
+        if (count_dev) {
+            const long long c = *count_dev;
+            S = c < S ? c : S;
+        }
+        for (long long i = (long long)(b - nb_box) * blockDim.x + threadIdx.x; i < S; i += (long long)nb_ext * blockDim.x) {
+            const int dy = shifts[2 * i], dx = shifts[2 * i + 1];
+            v[0] = min(v[0], dy); v[1] = max(v[1], dy); v[2] = min(v[2], dx); v[3] = max(v[3], dx);
+        }
+    }
+    for (int k = 0; k < 9; ++k)
+        for (int off = 32; off > 0; off >>= 1) {
+            const int o = __shfl_xor(v[k], off);
+            v[k] = k == 8 ? (v[k] | o) : (k & 1) ? max(v[k], o) : min(v[k], o);
+        }
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 9; ++k) red[wv][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        const int k = threadIdx.x;
+        int a = red[0][k];
+        for (int i = 1; i < 4; ++i) a = k == 8 ? (a | red[i][k]) : (k & 1) ? max(a, red[i][k]) : min(a, red[i][k]);
+        part[(size_t)b * PLAN_PART + k] = a;
+    }
+}
+// host_words: the calling thread's pinned buffer as the device sees it (nullptr: device words only); [15] = the sequence flag
+__global__ __launch_bounds__(256) void k_plan_finish(const int* __restrict__ part, int nb_box, int nb_ext, long long S,
+                                                     const int* __restrict__ count_dev, int* __restrict__ plan,
+                                                     volatile int* host_words, int seq)
+{
+    __shared__ int red[4][13];
+    const int wv = threadIdx.x >> 6;
+    // [0..3] box, [4..7] shift extents, [8..11] edge words (plan 9..12), [12] corner
+    int v[13] = {INT_MAX, INT_MIN, INT_MAX, INT_MIN, INT_MAX, INT_MIN, INT_MAX, INT_MIN, INT_MAX, INT_MIN, INT_MAX, INT_MIN, 0};
+    for (int b = threadIdx.x; b < nb_box; b += blockDim.x) {
+        const int* q = part + (size_t)b * PLAN_PART;
+        v[0] = min(v[0], q[0]); v[1] = max(v[1], q[1]); v[2] = min(v[2], q[2]); v[3] = max(v[3], q[3]);
+        v[8] = min(v[8], q[4]); v[9] = max(v[9], q[5]); v[10] = min(v[10], q[6]); v[11] = max(v[11], q[7]);
+        v[12] |= q[8];
+    }
+    for (int b = threadIdx.x; b < nb_ext; b += blockDim.x) {
+        const int* q = part + (size_t)(nb_box + b) * PLAN_PART;
+        v[4] = min(v[4], q[0]); v[5] = max(v[5], q[1]); v[6] = min(v[6], q[2]); v[7] = max(v[7], q[3]);
+    }
+    for (int k = 0; k < 13; ++k)
+        for (int off = 32; off > 0; off >>= 1) {
+            const int o = __shfl_xor(v[k], off);
+            v[k] = k == 12 ? (v[k] | o) : (k & 1) ? max(v[k], o) : min(v[k], o);
+        }
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 13; ++k) red[wv][k] = v[k];
+    __syncthreads();
+    // thread k < 14 folds and publishes plan word k (the stores into host memory are PCIe writes: one thread doing all fourteen
+    // in a row took 9 us); words: [0..7] as gathered, [8] count, [9..12] = gathered [8..11], [13] = corner flag
+    const int k = threadIdx.x;
+    if (k < PLAN_WORDS) {
+        int word;
+        if (k == 8) {
+            if (count_dev) {
+                const long long c = *count_dev;
+                S = c < S ? c : S;
+            }
+            word = (int)S;
+        } else {
+            const int src = k < 8 ? k : k - 1;                    // (edge words: "none seen" is (INT_MAX, INT_MIN), as k_plan_init leaves them)
+            int a = red[0][src];
+            for (int i = 1; i < 4; ++i) a = src == 12 ? (a | red[i][src]) : (src & 1) ? max(a, red[i][src]) : min(a, red[i][src]);
+            word = src == 12 ? (a ? 1 : 0) : a;
+        }
+        plan[k] = word;
+        if (host_words) {
+            host_words[k] = word;
+            __threadfence_system();
+        }
+    }
+    __syncthreads();
+    if (k == 0 && host_words) host_words[15] = seq;
+}
+
 // out[p][qy][qx] += sum_g slab[p * gstride + g][qx][qy]   (TS x TS tiles through LDS; blockIdx.z = plane p).  TS * TS threads per
 // tile, one element each: small images fold up to 64 slabs into a few dozen tiles (256^2: 64 tiles of 32 x 32), and with 256 threads
 // walking four rows each that took 38 us per image; fixed summation order (deterministic).  TS = 16 where 32 x 32 tiles would
 // not give every CU a workgroup (round 5: 256^2 folds 64 slabs in 64 workgroups otherwise -- 20 us of a 500 us image).
-template <int TS>
-__global__ __launch_bounds__(TS * TS) void k_slab_reduce(const float* __restrict__ slab, float* __restrict__ out, int pn, int ldq, int G,
-                                                         int gstride)
+template <int TS, int GS>
+__global__ __launch_bounds__(TS * TS * GS) void k_slab_reduce(const float* __restrict__ slab, float* __restrict__ out, int pn, int ldq, int G,
+                                                              int gstride)
 {
-    __shared__ float tile[TS][TS + 1];
+    // GS slab lanes per tile element: lane z sums the slabs z, z + GS, ... in order, the lanes are added in order (deterministic).
+    // Small images fold up to 64 slabs per element: with one thread walking all of them the 16.8 MB of config 1's fold took
+    // 20 us (0.85 TB/s, latency-bound); four lanes per element keep four times the loads in flight.
+    __shared__ float tile[GS][TS][TS + 1];
     slab += (size_t)blockIdx.z * gstride * ldq * pn;
     out += (size_t)blockIdx.z * pn * pn;
     const int qx0 = blockIdx.x * TS, qy0 = blockIdx.y * TS;
-    const int tx = threadIdx.x % TS, ty = threadIdx.x / TS;
+    const int e = threadIdx.x % (TS * TS), z = threadIdx.x / (TS * TS);
+    const int tx = e % TS, ty = e / TS;
     {
         const int qx = qx0 + ty, qy = qy0 + tx;
         float v = 0.f;
         if (qx < pn && qy < pn)
-            for (int gidx = 0; gidx < G; ++gidx) v += slab[((size_t)gidx * ldq + qx) * pn + qy];
-        tile[ty][tx] = v;
+            for (int gidx = z; gidx < G; gidx += GS) v += slab[((size_t)gidx * ldq + qx) * pn + qy];
+        tile[z][ty][tx] = v;
     }
     __syncthreads();
+    if (z != 0) return;
     const int qy = qy0 + ty, qx = qx0 + tx;
-    if (qx < pn && qy < pn) out[(size_t)qy * pn + qx] += tile[tx][ty];
+    if (qx < pn && qy < pn) {
+        float v = tile[0][tx][ty];
+        for (int k = 1; k < GS; ++k) v += tile[k][tx][ty];
+        out[(size_t)qy * pn + qx] += v;
+    }
 }
 static hipError_t launch_slab_reduce(const float* slab, float* out, int pn, int ldq, int planes, int G, int gstride, hipStream_t st)
 {
     const int t32 = (pn + 31) / 32;
     if ((long long)t32 * t32 * planes >= device_cus())
-        hipLaunchKernelGGL(k_slab_reduce<32>, dim3(t32, t32, planes), dim3(1024), 0, st, slab, out, pn, ldq, G, gstride);
+        hipLaunchKernelGGL((k_slab_reduce<32, 1>), dim3(t32, t32, planes), dim3(1024), 0, st, slab, out, pn, ldq, G, gstride);
+    else if (G >= 8)
+        hipLaunchKernelGGL((k_slab_reduce<16, 4>), dim3((pn + 15) / 16, (pn + 15) / 16, planes), dim3(1024), 0, st, slab, out, pn, ldq, G, gstride);
     else
-        hipLaunchKernelGGL(k_slab_reduce<16>, dim3((pn + 15) / 16, (pn + 15) / 16, planes), dim3(256), 0, st, slab, out, pn, ldq, G, gstride);
+        hipLaunchKernelGGL((k_slab_reduce<16, 1>), dim3((pn + 15) / 16, (pn + 15) / 16, planes), dim3(256), 0, st, slab, out, pn, ldq, G, gstride);
     return hipGetLastError();
 }
 
@@ -427,11 +550,13 @@ const SizeOps* size_ops(int log2n)
 // device timeline of a config-1 image (rocprofv3: __amd_rocclr_copyBuffer), a twelfth of the whole image; nullptr if the
 // allocation fails (then the stack array is used as before).  One buffer per calling thread, freed when the thread exits.
 struct PinnedWords {
-    int* p = nullptr;
+    int* p = nullptr;          // host address
+    int* dp = nullptr;         // the same buffer as kernels see it (device-mapped, coherent), nullptr if unavailable
+    int seq = 0;               // sequence number of the last k_plan_finish that was asked to publish here
     bool tried = false;
     ~PinnedWords() { if (p) (void)hipHostFree(p); }          // thread exit: a host application's short-lived worker threads do not leak
 };
-static int* pinned_words()
+static PinnedWords& pinned_state()
 {
     static thread_local PinnedWords pw;
     if (!pw.tried) {
@@ -441,12 +566,20 @@ static int* pinned_words()
         hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
         const bool swapped = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
         void* q = nullptr;
-        if (hipHostMalloc(&q, 64 * sizeof(int), hipHostMallocPortable) == hipSuccess) pw.p = (int*)q;
-        else (void)hipGetLastError();
+        if (hipHostMalloc(&q, 64 * sizeof(int), hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+            pw.p = (int*)q;
+            memset(q, 0, 64 * sizeof(int));
+            void* d = nullptr;
+            if (hipHostGetDevicePointer(&d, q, 0) == hipSuccess) pw.dp = (int*)d;
+            else (void)hipGetLastError();
+        } else {
+            (void)hipGetLastError();
+        }
         if (swapped) (void)hipThreadExchangeStreamCaptureMode(&mode);
     }
-    return pw.p;
+    return pw;
 }
+static int* pinned_words() { return pinned_state().p; }
 // n ints from the device to `host` (one small synchronising copy)
 static int read_words(const int* dev, int* host, int n, hipStream_t st)
 {
@@ -459,6 +592,43 @@ static int read_words(const int* dev, int* host, int n, hipStream_t st)
 }
 // Reads the plan words back.
 static int read_plan(const Workspace& w, int host[PLAN_WORDS], hipStream_t st) { return read_words(w.plan, host, PLAN_WORDS, st); }
+
+// The plan words of a call: one gathering launch over the pupil stack and the shift list, one single-block finish that also
+// publishes the words into this thread's pinned buffer, and the host's wait for its sequence flag.  The partial slots live in
+// the head of T (free until the source-point loop starts).
+static int gather_plan(const Workspace& w, const float2* P, int planes, int pn, int pe, const int* shifts, int64_t S,
+                       const int* count_dev, int pl[PLAN_WORDS], hipStream_t st)
+{
+    const int nb_box_x = (pn + BOX_ROWS_PER_BLOCK - 1) / BOX_ROWS_PER_BLOCK, nb_box = nb_box_x * planes;
+    int nb_ext = (int)((S + 1023) / 1024);
+    nb_ext = nb_ext < 1 ? 1 : (nb_ext > 256 ? 256 : nb_ext);
+    if ((size_t)(nb_box + nb_ext) * PLAN_PART * sizeof(int) > w.t_bytes) return LITHO_E_WORKSPACE;
+    int* part = (int*)w.T;
+    PinnedWords& pw = pinned_state();
+    const int seq = pw.dp ? (pw.seq = pw.seq == INT_MAX ? 1 : pw.seq + 1) : 0;
+    hipLaunchKernelGGL(k_plan_gather, dim3(nb_box + nb_ext), dim3(256), 0, st, P, pn, pn / 2 - pe / 4, pn / 2 + pe / 4, nb_box_x, nb_box,
+                       shifts, (long long)S, count_dev, nb_ext, part);
+    hipLaunchKernelGGL(k_plan_finish, dim3(1), dim3(256), 0, st, part, nb_box, nb_ext, (long long)S, count_dev, w.plan,
+                       (volatile int*)pw.dp, seq);
+    HIP_TRY(hipGetLastError());
+    if (pw.dp) {
+        // Poll the flag for a while (the wait is a few microseconds when the stream is otherwise idle -- an image sequence --
+        // and an interrupt-driven wake-up costs more than that); with a long queue in front, sleep in the runtime instead.
+        volatile int* hw = pw.p;
+        bool seen = false;
+        for (int spin = 0; spin < 50000 && !(seen = (hw[15] == seq)); ++spin) __builtin_ia32_pause();      // ~ 2 ms at most
+        if (!seen) {
+            HIP_TRY(hipStreamSynchronize(st));
+            seen = hw[15] == seq;
+        }
+        if (seen) {
+            for (int k = 0; k < PLAN_WORDS; ++k) pl[k] = hw[k];
+            return LITHO_OK;
+        }
+        // (a mapping the device could not write: fall through to the copy)
+    }
+    return read_plan(w, pl, st);
+}
 
 // HIP events of one profiled call; destroyed on every exit path.
 struct Mark { hipEvent_t ev; int kind; int items; };   // kind: -1 start, 0 after an x-pass, 1 after a y-pass
@@ -517,15 +687,19 @@ static hipError_t zero_slabs(float* slab, int pc, int G, int used, size_t slab_p
 
 // One chunk of planes (pc <= pp.PC pupils starting at Pc) over the whole source list: slabs zeroed, x-pass / y-pass
 // launch pairs batch by batch, slabs reduced INTO dst[0 .. pc) (each pn x pn, accumulated).
+// zero_dst: dst is scratch of the call (the coarse image) and starts at zero.
+// The zero fills (slabs, and dst when asked) are issued BEHIND the first batch's x-pass, which touches neither: right after the
+// planning read-back the device is idle and the host is the bottleneck -- every small launch in front of the first big kernel
+// is a few microseconds of idle device (config 1: 26 us of a 500 us image, profiles/r06_cfg1_timeline.txt); behind it they
+// are issued while the x-pass runs.
 static int accumulate_chunk(const AbbePlan& pp, const SizeOps* ops, const Workspace& w, const float2* twtab,
                             const float2* M, const float2* Pc, int pc, const int* shifts, int64_t S, int pn, float* dst,
-                            hipStream_t st, MarkList& marks, int64_t& nx)
+                            bool zero_dst, hipStream_t st, MarkList& marks, int64_t& nx)
 {
     const PassGeom& g = pp.g;
     const int variant = pp.variant, G = pp.G, xchunk = pp.xchunk;
     const int64_t bs = pp.bs;
     const size_t slab_plane = (size_t)g.nt * 4 * pn, plane_elems = (size_t)pn * pn;
-    HIP_TRY(zero_slabs(w.slab, pc, G, pp.slabs, slab_plane, st));
     bool fresh = true;                                     // start a new timing interval after memset / reduce
     int since_flush = 0;
     for (int64_t s0 = 0; s0 < S; s0 += bs) {
@@ -555,6 +729,11 @@ static int accumulate_chunk(const AbbePlan& pp, const SizeOps* ops, const Worksp
             q += np;
         }
         marks.add(0, nb * pc);
+        if (s0 == 0) {
+            HIP_TRY(zero_slabs(w.slab, pc, G, pp.slabs, slab_plane, st));
+            if (zero_dst) HIP_TRY(zero_async(dst, (size_t)pc * plane_elems * sizeof(float), st));
+            marks.add(-1, 0);                              // (the fills are not y-pass time)
+        }
         // ---- y-pass: every plane of the chunk, G groups each (fewer when the batch is shorter than G)
         // (a short tail batch, nb < G: as many groups as points -- but never more than the slabs this chunk zeroes and folds)
         int Geff = nb < G ? nb : G;
@@ -605,7 +784,10 @@ static int reconstruct_plane(const SizeOps* ops, const SizeOps* ops_c, const Wor
     HIP_TRY(ops->ypass_addreal(w.T, out, (float)(1.0 / ((double)pn * (double)pn)), w.twtab, gi, st));
     // 3. the Nyquist lines
     if (eg.len[0] > 0 || eg.len[1] > 0) {
-        const int chunks = (int)(S < GAM_CHUNKS ? S : GAM_CHUNKS);
+        // partial sums: one workgroup per chunk of source points.  At least 8 points per chunk (a short list in 1024 chunks of
+        // three points made k_nyquist_reduce the larger of the two kernels: config 1, 11 us to fold 4 MB of partials)
+        int64_t want = (S + 7) / 8;
+        const int chunks = (int)(want < 1 ? 1 : (want > GAM_CHUNKS ? GAM_CHUNKS : want));
         hipLaunchKernelGGL(k_nyquist_edges, dim3(chunks), dim3(256), 0, st, Pp, M, shifts, (long long)S, eg, w.gam);
         hipLaunchKernelGGL(k_nyquist_reduce, dim3(2 * 2 * EDGE_MAX / NYQ_RED_IDX), dim3(256), 0, st, w.gam, chunks);
         hipLaunchKernelGGL(k_nyquist_profiles, dim3((pn + 255) / 256, 2), dim3(256), 0, st, w.gam, w.twtab, eg, N);
@@ -618,9 +800,11 @@ static int reconstruct_plane(const SizeOps* ops, const SizeOps* ops_c, const Wor
 // Everything after the plan words are known: which kernels run and how the work is batched, the source-point loop, the
 // coarse-grid reconstruction.  `pl` = plan words in THIS grid's coordinates.
 static int accumulate_planned(const float2* M, const float2* P, int planes, const int* shifts, int64_t S, const int pl[PLAN_WORDS],
-                              int pn, int N, float* out, const Workspace& w, const Knobs& kn, const SizeOps* ops, hipStream_t st)
+                              int pn, int N, float* out, const Workspace& w, const Knobs& kn, const SizeOps* ops, hipStream_t st,
+                              bool tw2_ready = false)
 {
     int rc;
+    if (S <= 0) return LITHO_OK;
     const SizeOps* ops_c = size_ops(ilog2(pn));
     RunPlan rp;
     rc = plan_run(rp, w.t_bytes, kn, pl, pn, N, planes, S, device_cus(), ops_c != nullptr);
@@ -635,17 +819,16 @@ static int accumulate_planned(const float2* M, const float2* P, int planes, cons
     // profiling: ONE event per kernel-class boundary (E0 x E1 y E2 x E3 ...); consecutive events bracket the
     // launches of one pass over one batch.  (Two events recorded back to back alias on ROCm, so no begin/end pairs.)
     MarkList marks(g_profiling != 0, st);
-    if (coarse) hipLaunchKernelGGL(k_twiddle_table, dim3((pn + 255) / 256), dim3(256), 0, st, w.twtab2, pn);
+    if (coarse && !tw2_ready) hipLaunchKernelGGL(k_twiddle_table, dim3((pn + 255) / 256), dim3(256), 0, st, w.twtab2, pn);
     for (int p0 = 0; p0 < planes; p0 += run.PC) {
         const int pc = (planes - p0 < run.PC) ? planes - p0 : run.PC;
         const float2* Pc = P + (size_t)p0 * plane_elems;
         if (!coarse) {
-            rc = accumulate_chunk(pp, ops, w, w.twtab, M, Pc, pc, shifts, S, pn, out + (size_t)p0 * plane_elems, st, marks, nx);
+            rc = accumulate_chunk(pp, ops, w, w.twtab, M, Pc, pc, shifts, S, pn, out + (size_t)p0 * plane_elems, false, st, marks, nx);
             if (rc) return rc;
             continue;
         }
-        HIP_TRY(zero_async(w.ic, (size_t)pc * plane_elems * sizeof(float), st));
-        rc = accumulate_chunk(pc_plan, ops_c, w, w.twtab2, M, Pc, pc, shifts, S, pn, w.ic, st, marks, nx);
+        rc = accumulate_chunk(pc_plan, ops_c, w, w.twtab2, M, Pc, pc, shifts, S, pn, w.ic, true, st, marks, nx);
         if (rc) return rc;
         for (int q = 0; q < pc; ++q) {
             rc = reconstruct_plane(ops, ops_c, w, M, Pc + (size_t)q * plane_elems, shifts, S, pn, N, eg,
@@ -715,6 +898,10 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
         HIP_TRY(hipMemsetAsync(lo, 0xFF, (size_t)(hi - lo), st));
     }
     hipLaunchKernelGGL(k_twiddle_table, dim3((N + 255) / 256), dim3(256), 0, st, w.twtab, N);
+    // the coarse grid's table too, when a run at this size could take that path: in front of the planning read-back it costs
+    // nothing, behind it it is one more small launch between the host's wake-up and the first x-pass
+    const bool tw2_ready = pe == pn && kn.coarse && coarse_eligible(pn, N);
+    if (tw2_ready) hipLaunchKernelGGL(k_twiddle_table, dim3((pn + 255) / 256), dim3(256), 0, st, w.twtab2, pn);
     int pl[PLAN_WORDS];
     // (the record names the grid the edge words were looked up for -- record_run_size: a record made with the embedding off, or
     // with a smaller workspace, is not reused for an embedded run and vice versa -- and carries a format tag: words another
@@ -726,12 +913,7 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
     if (from_record) {
         rec_split = record_load(reuse->words, pl, sw);
     } else {
-        hipLaunchKernelGGL(k_plan_init, dim3(1), dim3(64), 0, st, w.plan);
-        hipLaunchKernelGGL(k_pupil_box, dim3((pn + BOX_ROWS_PER_BLOCK - 1) / BOX_ROWS_PER_BLOCK, planes), dim3(256), 0, st,
-                           P, pn, w.plan, pn / 2 - pe / 4, pn / 2 + pe / 4);
-        hipLaunchKernelGGL(k_shift_extents, dim3(256), dim3(256), 0, st, shifts, (long long)S, count_dev, w.plan);
-        HIP_TRY(hipGetLastError());
-        rc = read_plan(w, pl, st);                           // the ONE host wait of the image path
+        rc = gather_plan(w, P, planes, pn, pe, shifts, S, count_dev, pl, st);      // the ONE host wait of the image path
         if (rc) return rc;
         if (reuse) {
             record_store(reuse->words, pl, pe, nullptr);     // (a split, below, stores its ten words too)
@@ -786,7 +968,7 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
                 const int* lst = part == 0 ? list_a : list_b;
                 // part 0 cannot wrap (it may run embedded); part 1 wraps by construction: general mode at this size
                 if (part == 0 && pe != pn) rc = accumulate_embedded(M, P, planes, lst, n, plp, pn, pe, N, out, ws, ws_bytes, list_start, kn, ops, st);
-                else rc = accumulate_planned(M, P, planes, lst, n, plp, pn, N, out, ws_split, kn, ops, st);
+                else rc = accumulate_planned(M, P, planes, lst, n, plp, pn, N, out, ws_split, kn, ops, st, tw2_ready);
                 if (rc) return rc;
                 launches += g_last_plan[6];
             }
@@ -795,7 +977,7 @@ static int abbe_accumulate(const float2* M, const float2* P, int planes, const i
             return LITHO_OK;
         }
     }
-    if (pe == pn || !nowrap || kn.force_general) return accumulate_planned(M, P, planes, shifts, S, pl, pn, N, out, w, kn, ops, st);
+    if (pe == pn || !nowrap || kn.force_general) return accumulate_planned(M, P, planes, shifts, S, pl, pn, N, out, w, kn, ops, st, tw2_ready);
     return accumulate_embedded(M, P, planes, shifts, S, pl, pn, pe, N, out, ws, ws_bytes, 0, kn, ops, st);
 }
 

@@ -126,6 +126,33 @@ __global__ void k_row_write(const int64_t* __restrict__ bitmap, int pn, const in
     }
 }
 
+// The same write with the scan folded in (pn <= ROW_SUM_MAX): the wave of row r sums the raw counts of the rows in front of it
+// itself (at most 64 strided loads per lane) -- two launches per compaction instead of three; `counts` stays raw, the last row
+// leaves the total in counts[pn] (litho_abbe_accumulate_counted's count_dev).
+static constexpr int ROW_SUM_MAX = 4096;
+__global__ void k_row_write_sum(const int64_t* __restrict__ bitmap, int pn, int* __restrict__ counts,
+                                int32_t* __restrict__ shifts, long long capacity)
+{
+    const int row = blockIdx.x;
+    const int lane = threadIdx.x;
+    int before = 0;
+    for (int r = lane; r < row; r += 64) before += counts[r];
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off);
+    long long base = before;
+    const int c = pn / 2;
+    for (int c0 = 0; c0 < pn; c0 += 64) {
+        const int col = c0 + lane;
+        const bool lit = col < pn && bitmap[(size_t)row * pn + col] != 0;
+        const unsigned long long m = __ballot(lit);
+        if (lit) {
+            const long long pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos < capacity) { shifts[2 * pos] = row - c; shifts[2 * pos + 1] = col - c; }
+        }
+        base += __popcll(m);
+    }
+    if (row == pn - 1 && lane == 0) counts[pn] = (int)base;
+}
+
 // ---- pupil (pupil.py:46-111)
 struct ZTerm {
     int m, n, nk;
@@ -417,8 +444,12 @@ int litho_source_compact(const int64_t* bitmap, int pn, int32_t* shifts, int64_t
     if (!bitmap || !shifts || !scratch || pn < 1 || capacity < 0) return LITHO_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_row_counts, dim3(pn), dim3(256), 0, st, bitmap, pn, scratch);
-    hipLaunchKernelGGL(k_row_scan, dim3(1), dim3(1024), 0, st, scratch, pn);
-    hipLaunchKernelGGL(k_row_write, dim3(pn), dim3(64), 0, st, bitmap, pn, scratch, shifts, (long long)capacity);
+    if (pn <= ROW_SUM_MAX) {
+        hipLaunchKernelGGL(k_row_write_sum, dim3(pn), dim3(64), 0, st, bitmap, pn, scratch, shifts, (long long)capacity);
+    } else {
+        hipLaunchKernelGGL(k_row_scan, dim3(1), dim3(1024), 0, st, scratch, pn);
+        hipLaunchKernelGGL(k_row_write, dim3(pn), dim3(64), 0, st, bitmap, pn, scratch, shifts, (long long)capacity);
+    }
     HIP_TRY(hipGetLastError());
     if (!count_host) return LITHO_OK;                // asynchronous form: S stays on the device in scratch[pn]
     int total = 0;

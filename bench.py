@@ -331,6 +331,25 @@ PREDICTION = {"cfg1": {"single_gpu_ms": 0.55, "fixed_ms": 0.25}, "cfg2": {"singl
               "cfg3": {"single_gpu_ms": 1680.0, "fixed_ms": 1.5}, "cfg4": {"single_gpu_ms": 55600.0, "fixed_ms": 6.0},
               "cfg5": {"single_gpu_ms": 53900.0, "fixed_ms": 40.0}}
 XGMI_EFFECTIVE_GBS = 100.0
+PREDICTION_SOURCE = "literals in bench.py (profiles/r05_bench*.json)"
+
+
+def _load_prediction_inputs():
+    """single_gpu_ms from the round's committed bench line (profiles/prediction_inputs.json, written by scripts/collect_profiles.py
+    from profiles/<round>_bench.json) instead of literals that drift without notice (round-5 advice); fixed_ms stays as stated."""
+    global PREDICTION_SOURCE
+    path = os.path.join(ROOT, "profiles", "prediction_inputs.json")
+    try:
+        data = json.load(open(path))
+        for k, v in data.get("single_gpu_ms", {}).items():
+            if k in PREDICTION and isinstance(v, (int, float)) and v > 0:
+                PREDICTION[k] = dict(PREDICTION[k], single_gpu_ms=float(v))
+        PREDICTION_SOURCE = f"profiles/prediction_inputs.json ({data.get('source')})"
+    except Exception:
+        pass
+
+
+_load_prediction_inputs()
 
 
 def predicted_step(workload, world, allreduce_bytes):
@@ -340,7 +359,7 @@ def predicted_step(workload, world, allreduce_bytes):
     ar_ms = 2.0 * (world - 1) / world * allreduce_bytes / (XGMI_EFFECTIVE_GBS * 1e9) * 1e3 if world > 1 else 0.0
     ms = (p["single_gpu_ms"] - p["fixed_ms"]) / world + p["fixed_ms"] + ar_ms
     return {"predicted_step_ms": ms, "predicted_speedup": p["single_gpu_ms"] / ms, "predicted_allreduce_ms": ar_ms,
-            "single_gpu_ms_assumed": p["single_gpu_ms"],
+            "single_gpu_ms_assumed": p["single_gpu_ms"], "single_gpu_ms_source": PREDICTION_SOURCE,
             "note": "stated before the first N > 1 run: (single_gpu_ms - fixed_ms) / N + fixed_ms + ring all-reduce at "
                     f"{XGMI_EFFECTIVE_GBS:.0f} GB/s per link direction (DESIGN.md section 5); compare with ms_per_step and ranks.*"}
 
@@ -726,7 +745,10 @@ def main():
            "config": {"workload": (f"BASELINE {args.workload}: " if args.workload.startswith("cfg") else f"{args.workload}: ") + w.desc
                                   + (f" [{shard_note}]" if shard_note else ""),
                       "pn": pn, "fft_n": N, "executed_fft_n": n_exec, "source_points": S, "source_points_full": S_full, "planes": planes,
-                      "points_per_rank": math.ceil(S / world), "pixel_size": PS, "wavelength": WL, "NA": NA,
+                      "points_per_rank": math.ceil(S / world),
+                      # how often this process ran the step's kernels (warm-up + timed + the event pass of short steps + the profiled
+                      # one): scripts/pmc_traffic.py divides whole-process counters by it
+                      "step_executions": args.warmup + args.steps + (args.steps if short else 0) + 1, "pixel_size": PS, "wavelength": WL, "NA": NA,
                       "parallelism": f"source-point shards x{world}, one all-reduce" if world > 1 else "single GPU",
                       "plan": plan, "image_shape": list(image.shape)},
            "target_abs": {"per_gpu": TARGET_ABS_PER_GPU, "n_gpus": world, "value_over_target": value / (TARGET_ABS_PER_GPU * world),

@@ -40,3 +40,22 @@ if traffic:
         v["commit"] = commit          # the source tree the counters were captured from (this script runs right after the capture)
     json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     print("traffic.json:", {k: (round(v["xpass_bytes_per_item"] / 1e6, 2), round(v["ypass_bytes_per_item"] / 1e6, 2)) for k, v in traffic.items()})
+
+# single-GPU step times of this round's default bench line -> the inputs of bench.py's N-GPU prediction (round-5 advice: they were
+# literals that drift without notice).  cfg4's whole-list time = 8 x its measured shard (the default line runs shard 0 of 8).
+bj = os.path.join(dst, f"{R}_bench.json")
+if os.path.exists(bj):
+    try:
+        line = json.loads([ln for ln in open(bj) if ln.startswith("{")][-1])
+        single = {"cfg3": line.get("median_ms_per_step") or line["ms_per_step"]}
+        for e in line.get("extra_workloads", []):
+            name = e.get("workload", "")
+            for k in ("cfg1", "cfg2", "cfg4", "cfg5"):
+                if name.startswith(f"BASELINE {k}:") and "ms_per_step" in e:
+                    ms = e.get("median_ms_per_step") or e["ms_per_step"]
+                    single[k] = ms * 8.0 if k == "cfg4" else ms
+        json.dump({"source": f"profiles/{R}_bench.json: median_ms_per_step of the headline and of every extra workload (cfg4 = 8 x shard 0/8)",
+                   "single_gpu_ms": single}, open(os.path.join(dst, "prediction_inputs.json"), "w"), indent=1)
+        print("prediction_inputs.json:", {k: round(v, 2) for k, v in single.items()})
+    except Exception as exc:
+        print("prediction inputs skipped:", exc)

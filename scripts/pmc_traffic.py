@@ -16,7 +16,8 @@ GEOMETRY_KEYS = ("batch", "groups_per_plane", "xchunk", "planes_in_flight", "coa
 root, bench_json, workload = sys.argv[1:4]
 bench = json.loads([ln for ln in open(bench_json) if ln.startswith("{")][-1])
 cfg = bench["config"]
-items_total = 2 * cfg["source_points"] * cfg["planes"]          # timed step + profiled step of bench.py
+# every execution of the step in that process: timed step + profiled step (+ warm-up and the event pass of short steps, if any)
+items_total = cfg.get("step_executions", 2) * cfg["source_points"] * cfg["planes"]
 
 
 def per_class(counter, sub):

@@ -24,8 +24,11 @@ def test_prediction_model():
     one = b.predicted_step("cfg3", 1, 2048 * 2048 * 4)
     assert one["predicted_speedup"] == 1.0 and one["predicted_allreduce_ms"] == 0.0
     eight = b.predicted_step("cfg3", 8, 2048 * 2048 * 4)
-    # (1680 - 1.5) / 8 + 1.5 + 2 * 7/8 * 16.8 MB / 100 GB/s
-    assert abs(eight["predicted_step_ms"] - ((1680.0 - 1.5) / 8 + 1.5 + 2 * 7 / 8 * 2048 * 2048 * 4 / 100e9 * 1e3)) < 1e-9
+    # (single - fixed) / 8 + fixed + 2 * 7/8 * 16.8 MB / 100 GB/s; single = the round's committed bench line
+    # (profiles/prediction_inputs.json, written by scripts/collect_profiles.py) or the literal
+    single, fixed = b.PREDICTION["cfg3"]["single_gpu_ms"], b.PREDICTION["cfg3"]["fixed_ms"]
+    assert 1500.0 < single < 1900.0 and fixed == 1.5 and eight["single_gpu_ms_assumed"] == single and eight["single_gpu_ms_source"]
+    assert abs(eight["predicted_step_ms"] - ((single - fixed) / 8 + fixed + 2 * 7 / 8 * 2048 * 2048 * 4 / 100e9 * 1e3)) < 1e-9
     assert 7.5 < eight["predicted_speedup"] < 8.0
     assert 7.8 < b.predicted_step("cfg4", 8, 4096 * 4096 * 4)["predicted_speedup"] < 8.0
     assert b.predicted_step("odd2000", 8, 1) is None

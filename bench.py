@@ -361,7 +361,7 @@ def predicted_step(workload, world, allreduce_bytes):
     return {"predicted_step_ms": ms, "predicted_speedup": p["single_gpu_ms"] / ms, "predicted_allreduce_ms": ar_ms,
             "single_gpu_ms_assumed": p["single_gpu_ms"], "single_gpu_ms_source": PREDICTION_SOURCE,
             "note": "stated before the first N > 1 run: (single_gpu_ms - fixed_ms) / N + fixed_ms + ring all-reduce at "
-                    f"{XGMI_EFFECTIVE_GBS:.0f} GB/s per link direction (DESIGN.md section 5); compare with ms_per_step and ranks.*"}
+                    f"{XGMI_EFFECTIVE_GBS:.0f} GB/s per link direction (DESIGN.md section 7); compare with ms_per_step and ranks.*"}
 
 
 CPU_SAMPLE_POINTS = {256: 64, 1024: 16, 2048: 8, 4096: 4}      # BASELINE.md / SURVEY 8d: K source points per grid size

@@ -116,7 +116,7 @@ int litho_abbe_embedded_size(int pn, int N, int *size_host);
  * enough to repay it, the loop runs pn-point transforms on the grid q = 2 v and the fine image is reconstructed
  * once per call and plane; same result to rounding.  Environment, read once per call:
  * LITHO_ABBE_COARSE = 0 (never) / 1 (default: by source count) / 2 (whenever eligible); the other LITHO_ABBE_*
- * variables select kernel variants for parity tests and tuning (DESIGN.md section 8). */
+ * variables select kernel variants for parity tests and tuning (DESIGN.md section 6). */
 int litho_abbe_accumulate(const void *maskFT, const void *pupil, int planes,
                           const int32_t *shifts, int64_t S, int pn, int N, float *out,
                           void *workspace, size_t workspace_bytes, void *stream);
@@ -157,7 +157,7 @@ int litho_abbe_accumulate_planned(const void *maskFT, const void *pupil, int pla
  * The reference has no counterpart (its loop has nothing to tune, imageformation.py:62-67); this is how tests, bench.py
  * and embedding applications select an evaluation path per CALL -- per thread, per stream -- without touching
  * LITHO_ABBE_* variables.  Every field: < 0 = not set (the LITHO_ABBE_<NAME> environment variable if present, else the
- * default); the meanings are those of DESIGN.md section 8.  `size` = sizeof(litho_abbe_options) as the caller compiled it
+ * default); the meanings are those of DESIGN.md section 6.  `size` = sizeof(litho_abbe_options) as the caller compiled it
  * (fields beyond it count as not set, so the struct can grow).  plan, options, count_dev and count_host may each be NULL
  * (count_dev NULL: `capacity` is the number of source points). */
 typedef struct litho_abbe_options {
@@ -168,7 +168,7 @@ typedef struct litho_abbe_options {
     int32_t xchunk;          /* source points per x-pass workgroup (0 = automatic) */
     int32_t tile;            /* T tile width in columns: 4, 8, 16 (0 = automatic) */
     int32_t plane_chunk;     /* planes of a stack in flight per launch pair (0 = automatic: 1) */
-    int32_t w64, rect, w64_8192, xsplit, xrect, w64x, gcombine, rowpairs;   /* kernel families, DESIGN.md section 8 */
+    int32_t w64, rect, w64_8192, xsplit, xrect, w64x, gcombine, rowpairs;   /* kernel families, DESIGN.md section 6 */
     int32_t force_generic, force_general;                                  /* runtime-predicated kernels / modular gather */
     int32_t poison;          /* 1: scratch starts the call as NaN bit patterns (tests) */
     int32_t embed;           /* 0: run mask sizes other than N and N / 2 on the generic kernels at their own size instead of

@@ -239,7 +239,7 @@ _option_stack = threading.local()
 def engineOptions(**kw):
     """`with engineOptions(coarse=2, batch=7): ...` -- launch-planner options for every Abbe call of THIS thread inside the
     block (nested blocks merge, inner wins), passed through the C ABI's litho_abbe_options; nothing touches os.environ.
-    Names = the LITHO_ABBE_* variables of DESIGN.md section 8 in lower case."""
+    Names = the LITHO_ABBE_* variables of DESIGN.md section 6 in lower case."""
     Options.make(kw)                                       # validate the names now
     stack = getattr(_option_stack, "v", None)
     if stack is None:

@@ -12,7 +12,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- pyt
 python3 bench.py --workload cfg1 > $O/bench_cfg1.json 2>/dev/null
 python3 bench.py --workload cfg2 > $O/bench_cfg2.json 2>/dev/null
 python3 bench.py --workload cfg4 --shard 0/8 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_cfg4_shard0of8.json 2>/dev/null
-# per-rank work of the other 8-GPU runs (DESIGN.md section 5: the predicted 8-GPU step is built from these)
+# per-rank work of the other 8-GPU runs (DESIGN.md section 7: the predicted 8-GPU step is built from these)
 python3 bench.py --workload cfg3 --shard 0/8 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_cfg3_shard0of8.json 2>/dev/null
 python3 bench.py --workload cfg5 --shard 0/8 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_cfg5_shard0of8.json 2>/dev/null
 # SKIP_PMC=1: bench lines and kernel stats only (e.g. after profiles/traffic.json has been refreshed from the PMC passes)

@@ -112,7 +112,7 @@ def test_embedded_size_rule():
         pe = L.embeddedSize(pn, N)
         assert pe == pn or ((pe - pn) % 2 == 0 and pe in (N, N // 2) and pe > pn)
     with pytest.raises(ValueError):
-        L.embeddedSize(1001, 2048)                     # odd sizes are not served at all (DESIGN.md section 9)
+        L.embeddedSize(1001, 2048)                     # odd sizes are not served at all (DESIGN.md section 10)
 
 
 def test_synthetic_masks_are_reproducible():

@@ -1,5 +1,5 @@
 """Copy the summaries of a profile round from gpurun_out/<round>/ (scratch) into profiles/ (tracked):
-    python scripts/collect_profiles.py r03
+    python scripts/collect_profiles.py r03 [commit of the snapshot]
 bench lines, the rocprofv3 kernel stats of the default command, the PMC summaries, and profiles/traffic.json
 (merged from the per-workload traffic_*.json of scripts/pmc_traffic.sh)."""
 import glob
@@ -31,7 +31,8 @@ for p in sorted(glob.glob(os.path.join(src, "traffic_cfg*.json"))):
 if traffic:
     import subprocess
     try:
-        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+        # (optional second argument: the commit the gpurun snapshot was taken at, when later commits -- documents only -- exist)
+        commit = sys.argv[2] if len(sys.argv) > 2 else subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
         if subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "lithographysimulator_amd"], text=True).strip():
             commit += "+uncommitted"
     except Exception:

@@ -570,8 +570,11 @@ static PinnedWords& pinned_state()
             pw.p = (int*)q;
             memset(q, 0, 64 * sizeof(int));
             void* d = nullptr;
-            if (hipHostGetDevicePointer(&d, q, 0) == hipSuccess) pw.dp = (int*)d;
-            else (void)hipGetLastError();
+            // LITHO_ABBE_NO_MAPPED_PLAN=1 (tests): behave as if the buffer could not be mapped -- the copy + stream-wait fallback
+            const char* off = getenv("LITHO_ABBE_NO_MAPPED_PLAN");
+            if (off && off[0] == '1') d = nullptr;
+            else if (hipHostGetDevicePointer(&d, q, 0) != hipSuccess) { d = nullptr; (void)hipGetLastError(); }
+            pw.dp = (int*)d;
         } else {
             (void)hipGetLastError();
         }

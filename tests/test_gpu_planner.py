@@ -778,3 +778,53 @@ def test_seeded_fuzz_4096_against_the_float64_oracle(L, dev):
     # 8192-point kernels
     assert any(k.startswith("k_ypass_coop") for k in kernels) and any(k.startswith("k_xpass_abbe<12, 0, true") for k in kernels), sorted(kernels)
     assert any(k.startswith(("k_xpass_split<13>", "k_ypass_pair<13", "k_ypass_acc<13", "k_xpass_abbe<13")) for k in kernels), sorted(kernels)
+
+
+def test_plan_words_arrive_by_both_read_back_routes():
+    """The planning read-back (round 6): the 14 plan words normally arrive in the calling thread's pinned, device-MAPPED buffer,
+    published by k_plan_finish under a sequence flag the host polls; when the buffer cannot be mapped
+    (LITHO_ABBE_NO_MAPPED_PLAN=1 emulates that) they come through the copy + stream wait.  Both routes in fresh processes:
+    the same plan (box, batch, coarse grid, source count) and bit-identical images for a centred and a shifted (split) source,
+    a stack, a single source point, and ten calls in a row (the sequence flag must never be taken for the previous call's)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from helpers import ROOT
+    code = r"""
+import hashlib, json, sys, torch
+sys.path.insert(0, %r)
+import lithographysimulator_amd as L
+from lithographysimulator_amd import _native as nat
+from lithographysimulator_amd.synthetic import bernoulli_mask
+dev = torch.device("cuda", 0)
+out = []
+def digest(t): return hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()[:16]
+for pn, sx, planes in ((256, 0.0, 1), (512, 0.25, 1), (256, 0.0, 3)):
+    mask = L.Mask(bernoulli_mask(pn), 25, dev)
+    mft = mask.fraunhofer(193., True)
+    bm = (L.LightSource(0.0, 0.5, pn, 0.7, device=dev) if sx == 0.0 else L.LightSource(0.4, 0.8, pn, 0.7, sx, -0.5, dev)).generateAnnular()
+    ab = torch.tensor([0, 0, 0.01, 0, 60, 0.01], dtype=torch.float16)
+    pf = (L.Pupil(pn, 193., 0.7, ab, dev).generatePupilFunction() if planes == 1 else
+          L.throughFocusPupils(pn, 193., 0.7, ab, [-50.0, 0.0, 70.0], dev))
+    for rep in range(10 if pn == 256 and planes == 1 else 1):
+        img = L.abbeImage(mask, mft, pf, bm, 25, mask.deltaK, 193., True, dev)
+        out.append([digest(img), {k: int(v) for k, v in nat.last_plan().items()}])
+    sh = L.sourceShifts(bm, pn)
+    one = L.abbeIntensity(mft, pf, sh[7:8], 2 * pn)
+    out.append([digest(one), {k: int(v) for k, v in nat.last_plan().items()}])
+print(json.dumps(out))
+""" % ROOT
+    res = {}
+    for route in ("mapped", "copy"):
+        env = dict(os.environ)
+        env.pop("LITHO_ABBE_NO_MAPPED_PLAN", None)
+        if route == "copy":
+            env["LITHO_ABBE_NO_MAPPED_PLAN"] = "1"
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-1500:]
+        res[route] = json.loads([l for l in r.stdout.splitlines() if l.startswith("[")][-1])
+    assert res["mapped"] == res["copy"]
+    plans = [p for _, p in res["mapped"]]
+    assert plans[0]["coarse_grid"] == 1 and plans[0]["box_rows"] == 129 and len({d for d, _ in res["mapped"][:10]}) == 1
+    assert any(p["planned_from_record"] == 2 for p in plans)               # the shifted source was split

@@ -780,7 +780,8 @@ def main():
         del w, image
         torch.cuda.empty_cache()
         extras = []
-        for name, kw in (("cfg1", dict(steps=200, warm_steps=20, profile_points=1 << 30)),     # (0.46 ms steps: 20 of them are 9 ms, inside the clock ramp after an idle gap) ("cfg2", dict(steps=2, profile_points=4800)),
+        # (cfg1: 0.46 ms steps -- 20 of them are 9 ms, inside the clock ramp after an idle gap: 200)
+        for name, kw in (("cfg1", dict(steps=200, warm_steps=20, profile_points=1 << 30)), ("cfg2", dict(steps=2, profile_points=4800)),
                          ("cfg4", dict(shard=(0, 8), steps=2, warm_points=600, profile_points=2400)),
                          ("cfg5", dict(steps=2 if args.steps >= 5 else 1, warm_points=240, profile_points=240)),
                          ("odd2000", dict(steps=1, warm_points=480, profile_points=480))):

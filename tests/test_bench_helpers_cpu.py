@@ -117,3 +117,15 @@ def test_check_in_names_the_missing_rank_and_exits_non_zero():
     assert out.returncode == 3, (out.returncode, out.stderr[-500:])
     assert "phase one complete" in out.stdout and "not reached" not in out.stdout
     assert "rank 0" in out.stderr and "rank(s) [1] of 2 did not arrive" in out.stderr and "'pair'" in out.stderr
+
+
+def test_default_line_carries_every_baseline_config():
+    """The default run's extra_workloads must name configs 1, 2, 4 (shard) and 5 (+ odd2000) -- read from the source's syntax tree
+    (the run itself takes minutes): a comment once swallowed an entry of the tuple."""
+    import ast
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    names = None
+    for node in ast.walk(tree):
+        if isinstance(node, ast.For) and isinstance(node.target, ast.Tuple) and [getattr(t, "id", None) for t in node.target.elts] == ["name", "kw"]:
+            names = [elt.elts[0].value for elt in node.iter.elts]
+    assert names == ["cfg1", "cfg2", "cfg4", "cfg5", "odd2000"], names

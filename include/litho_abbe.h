@@ -218,7 +218,7 @@ int litho_abbe_plan_dry_run(int pn, int N, int planes, const int32_t *plan_words
                             const litho_abbe_options *options, int cus, size_t workspace_bytes, litho_abbe_dry_run *result);
 
 /* ---- Single-point field: calculateFFTAerial(pf, maskFFFT, pixelNumber, N)
- * (imageformation.py:32-45).  field = complex64 [pn,pn].  Reads back 16 bytes. */
+ * (imageformation.py:32-45).  field = complex64 [pn,pn].  Reads back the pupil's support box (56 bytes). */
 int litho_abbe_field(const void *pf, const void *maskFT, int pn, int N, void *field,
                      void *workspace, size_t workspace_bytes, void *stream);
 

@@ -50,86 +50,16 @@ __global__ void k_twiddle_table(float2* tab, int N)
 }
 
 // (plan words: abbe_plan.hpp)
-__global__ void k_plan_init(int* plan)
-{
-    if (threadIdx.x < 8) plan[threadIdx.x] = (threadIdx.x & 1) ? INT_MIN : INT_MAX;
-    if (threadIdx.x == 8) plan[8] = 0;
-    if (threadIdx.x >= 9 && threadIdx.x <= 12) plan[threadIdx.x] = (threadIdx.x & 1) ? INT_MAX : INT_MIN;
-    if (threadIdx.x == 13) plan[13] = 0;
-}
-
-// Bounding box of the non-zero pupil samples over all planes: grid (row blocks, planes), each block scans
-// BOX_ROWS_PER_BLOCK rows of one plane; one atomic quadruple per block that saw a non-zero.
 static constexpr int BOX_ROWS_PER_BLOCK = 8;
-__global__ __launch_bounds__(256) void k_pupil_box(const float2* __restrict__ P, int pn, int* plan, int e_lo, int e_hi)
-{
-    __shared__ int red[4][4];
-    const int row0 = blockIdx.x * BOX_ROWS_PER_BLOCK;
-    const float2* plane = P + (size_t)blockIdx.y * pn * pn;
-    int rmin = INT_MAX, rmax = INT_MIN, cmin = INT_MAX, cmax = INT_MIN;
-    for (int row = row0; row < min(pn, row0 + BOX_ROWS_PER_BLOCK); ++row) {
-        const float2* r = plane + (size_t)row * pn;
-        for (int j = threadIdx.x; j < pn; j += blockDim.x) {
-            const float2 v = r[j];
-            if (v.x != 0.f || v.y != 0.f) {
-                rmin = min(rmin, row); rmax = max(rmax, row);
-                cmin = min(cmin, j); cmax = max(cmax, j);
-                // edges of the natural box of the grid the engine will RUN at (e_lo, e_hi = c -+ pn/4, or -+ pe/4 of the padded
-                // grid of an embedded evaluation -- then possibly outside this array): a handful of samples, direct atomics
-                const bool ecol = (j == e_hi || j == e_lo), erow = (row == e_hi || row == e_lo);
-                if (ecol) { atomicMin(&plan[9], row); atomicMax(&plan[10], row); }
-                if (erow) { atomicMin(&plan[11], j); atomicMax(&plan[12], j); }
-                if (ecol && erow) atomicExch(&plan[13], 1);
-            }
-        }
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        rmin = min(rmin, __shfl_xor(rmin, off)); rmax = max(rmax, __shfl_xor(rmax, off));
-        cmin = min(cmin, __shfl_xor(cmin, off)); cmax = max(cmax, __shfl_xor(cmax, off));
-    }
-    const int wv = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { red[wv][0] = rmin; red[wv][1] = rmax; red[wv][2] = cmin; red[wv][3] = cmax; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int i = 1; i < 4; ++i) {
-            rmin = min(rmin, red[i][0]); rmax = max(rmax, red[i][1]);
-            cmin = min(cmin, red[i][2]); cmax = max(cmax, red[i][3]);
-        }
-        if (rmax >= 0) {
-            atomicMin(&plan[0], rmin); atomicMax(&plan[1], rmax);
-            atomicMin(&plan[2], cmin); atomicMax(&plan[3], cmax);
-        }
-    }
-}
-
-// S comes from the host, or -- asynchronous image path -- from the device word litho_source_compact left behind
-// (count_dev, clamped to `S` = the capacity); plan[8] returns the count actually used.
-__global__ void k_shift_extents(const int* __restrict__ shifts, long long S, const int* __restrict__ count_dev, int* plan)
-{
-    if (count_dev) {
-        const long long c = *count_dev;
-        S = c < S ? c : S;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) plan[8] = (int)S;
-    int ymin = INT_MAX, ymax = INT_MIN, xmin = INT_MAX, xmax = INT_MIN;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (long long)gridDim.x * blockDim.x) {
-        const int dy = shifts[2 * i], dx = shifts[2 * i + 1];
-        ymin = min(ymin, dy); ymax = max(ymax, dy); xmin = min(xmin, dx); xmax = max(xmax, dx);
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        ymin = min(ymin, __shfl_xor(ymin, off)); ymax = max(ymax, __shfl_xor(ymax, off));
-        xmin = min(xmin, __shfl_xor(xmin, off)); xmax = max(xmax, __shfl_xor(xmax, off));
-    }
-    if ((threadIdx.x & 63) == 0 && ymin != INT_MAX) {
-        atomicMin(&plan[4], ymin); atomicMax(&plan[5], ymax);
-        atomicMin(&plan[6], xmin); atomicMax(&plan[7], xmax);
-    }
-}
 
 // ----------------------------------------------------------------------------------
-// The same plan words in ONE gathering launch + one single-block finish (round 6): k_plan_init + k_pupil_box + k_shift_extents
-// + the runtime's copy kernel were four dependent small launches in front of the one host wait of an image -- at 256^2 a tenth
-// of the image.  Every block writes its partial extrema to its own 16-int slot (no atomics, so nothing to initialise); the
+// The plan words in ONE gathering launch + one single-block finish (round 6; until then k_plan_init + k_pupil_box +
+// k_shift_extents with atomics on the words + the runtime's copy kernel: four dependent small launches in front of the one host
+// wait of an image -- at 256^2 a tenth of the image).  Box blocks: bounding box of the non-zero pupil samples over all planes and
+// the supports on the edges of the natural box of the grid the engine will RUN at (e_lo, e_hi = c -+ pn/4, or -+ pe/4 of the
+// padded grid of an embedded evaluation -- then possibly outside this array); extent blocks: extrema of the shift list, whose
+// length comes from the host or -- asynchronous image path -- from the device word litho_source_compact left behind (count_dev,
+// clamped to `S` = the capacity).  Every block writes its partial extrema to its own 16-int slot (no atomics, so nothing to initialise); the
 // finish block folds them, stores the words on the device AND into the calling thread's pinned, device-mapped host buffer, and
 // raises a sequence flag there, which the host polls (no copy kernel, no interrupt-driven wake-up for a wait of microseconds).
 //   box blocks  [0, nb_box): BOX_ROWS_PER_BLOCK rows of one plane -> slot {rmin, rmax, cmin, cmax, e9, e10, e11, e12, corner}
@@ -223,7 +153,7 @@ __global__ __launch_bounds__(256) void k_plan_finish(const int* __restrict__ par
             }
             word = (int)S;
         } else {
-            const int src = k < 8 ? k : k - 1;                    // (edge words: "none seen" is (INT_MAX, INT_MIN), as k_plan_init leaves them)
+            const int src = k < 8 ? k : k - 1;                    // (edge words: "none seen" is (INT_MAX, INT_MIN))
             int a = red[0][src];
             for (int i = 1; i < 4; ++i) a = src == 12 ? (a | red[i][src]) : (src & 1) ? max(a, red[i][src]) : min(a, red[i][src]);
             word = src == 12 ? (a ? 1 : 0) : a;
@@ -1028,12 +958,8 @@ static int abbe_field(const float2* pf, const float2* M, int pn, int N, float2* 
     Workspace w;
     if (!carve(ws, ws_bytes, pn, N, w)) return LITHO_E_WORKSPACE;
     hipLaunchKernelGGL(k_twiddle_table, dim3((N + 255) / 256), dim3(256), 0, st, w.twtab, N);
-    hipLaunchKernelGGL(k_plan_init, dim3(1), dim3(64), 0, st, w.plan);
-    hipLaunchKernelGGL(k_pupil_box, dim3((pn + BOX_ROWS_PER_BLOCK - 1) / BOX_ROWS_PER_BLOCK, 1), dim3(256), 0, st, pf, pn, w.plan,
-                       pn / 2 - pn / 4, pn / 2 + pn / 4);
-    HIP_TRY(hipGetLastError());
     int pl[PLAN_WORDS];
-    rc = read_plan(w, pl, st);
+    rc = gather_plan(w, pf, 1, pn, pn, nullptr, 0, nullptr, pl, st);      // the pupil's support box (no shift list)
     if (rc) return rc;
     if (pl[1] < pl[0]) {                                      // zero pupil -> zero field
         HIP_TRY(zero_async(field, (size_t)pn * pn * sizeof(float2), st));

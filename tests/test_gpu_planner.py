@@ -514,7 +514,7 @@ def test_shifted_source_split_at_the_large_sizes(L, dev, pn, K):
 
 
 def _plan_words_of(pupils, shifts, pe):
-    """The 14 plan words the engine reads back (k_pupil_box + k_shift_extents), computed on the host from the tensors: support box
+    """The 14 plan words the engine reads back (k_plan_gather + k_plan_finish), computed on the host from the tensors: support box
     of the non-zero pupil samples over all planes, shift extents, count, supports on the natural-box edges of the grid the engine
     will run at (pe), corner flag."""
     INT_MAX, INT_MIN = 2**31 - 1, -2**31

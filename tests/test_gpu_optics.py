@@ -75,6 +75,24 @@ def test_source_compaction_edge_cases(L, dev):
         L.sourceShifts(torch.ones((32, 32), dtype=torch.int64, device=dev), pn)
 
 
+@pytest.mark.parametrize("pn", [2, 62, 1000, 4096, 4098, 8192])
+def test_source_compaction_on_both_sides_of_the_fused_scan(L, dev, pn):
+    """litho_source_compact runs two launches up to pn = 4096 (the row-offset scan folded into the write, round 6) and three
+    above: random sparse bitmaps (empty rows, full rows, first / last pixel lit) against torch.argwhere (imageformation.py:59) on
+    both sides of the switch, with the device-side count of the asynchronous form."""
+    gen = torch.Generator().manual_seed(pn)
+    bm = (torch.rand(pn, pn, generator=gen) < (0.3 if pn <= 1000 else 0.002)).to(torch.int64)
+    bm[0, 0] = 1; bm[pn - 1, pn - 1] = 1
+    if pn >= 62:
+        bm[5] = 0; bm[7] = 1; bm[pn - 2] = 0
+    want = (torch.argwhere(bm) - pn // 2).to(torch.int32)
+    got = L.sourceShifts(bm.to(dev), pn)
+    assert got.dtype == torch.int32 and torch.equal(got.cpu(), want)
+    from lithographysimulator_amd.lightsource import sourceShiftsAsync
+    sh, count = sourceShiftsAsync(bm.to(dev), pn)
+    assert int(count.item()) == want.shape[0] and torch.equal(sh[:want.shape[0]].cpu(), want)
+
+
 @pytest.mark.parametrize("pn", [64, 256])
 @pytest.mark.parametrize("name", list(PUPIL_CASES))
 def test_pupils(golden, L, dev, pn, name):

@@ -533,6 +533,7 @@ def main():
     torch.cuda.set_device(dev)
     group = None
     store = None
+    backend_fallback = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # First contact with a multi-GPU node must end in minutes with the guilty rank named, not at the lease limit: the
@@ -541,12 +542,35 @@ def main():
         tmo = timedelta(seconds=RENDEZVOUS_TIMEOUT_S)
         try:
             if backend == "nccl":
+                if os.environ.get("LITHO_BENCH_FORCE_RCCL_FAIL") == "1":     # test hook: the fallback below, on a one-GPU box
+                    raise RuntimeError("LITHO_BENCH_FORCE_RCCL_FAIL=1")
                 dist.init_process_group("nccl", device_id=dev, timeout=tmo)      # "nccl" is RCCL on ROCm
+                probe = torch.ones(1, dtype=torch.float32, device=dev)           # first contact: one tiny collective, checked
+                dist.all_reduce(probe)
+                if float(probe.item()) != float(world):
+                    raise RuntimeError(f"RCCL probe all-reduce returned {float(probe.item())}, expected {world}")
             else:
                 dist.init_process_group(backend, timeout=tmo)
         except Exception as exc:
-            die(rank, f"rendezvous of {world} ranks at {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')} failed "
-                      f"within {RENDEZVOUS_TIMEOUT_S} s", exc)
+            if backend != "nccl" or os.environ.get("LITHO_BENCH_NO_FALLBACK") == "1":
+                die(rank, f"rendezvous of {world} ranks at {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')} failed "
+                          f"within {RENDEZVOUS_TIMEOUT_S} s", exc)
+            # RCCL could not be brought up on this node: a record with the collective staged through the host (gloo: the 16.8 MB
+            # image of config 3 costs tens of milliseconds that way) says more than no record -- LABELLED as such in `ranks`.
+            sys.stderr.write(f"bench.py: rank {rank}: RCCL initialisation failed ({exc!r}); falling back to a gloo group "
+                             "(all-reduce staged through the host)\n")
+            backend_fallback = repr(exc)
+            try:
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+            except Exception:
+                pass
+            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+            backend = "gloo"
+            try:
+                dist.init_process_group("gloo", timeout=tmo)
+            except Exception as exc2:
+                die(rank, f"gloo fallback rendezvous of {world} ranks failed as well", exc2)
         group = dist.group.WORLD
         assert dist.get_world_size() == world == args.gpus, (dist.get_world_size(), world, args.gpus)
         try:
@@ -667,6 +691,7 @@ def main():
                  "allreduce_wait_ms_max": max(r[2] for r in rows), "allreduce_wait_ms_min": min(r[2] for r in rows),
                  "allreduce_bytes": int(part.numel() * 4),
                  "world": dist.get_world_size(), "backend": backend + (" (RCCL)" if backend == "nccl" else ""), "rccl_version": rccl,
+                 "backend_fallback": backend_fallback,          # not None: RCCL could not be initialised, the all-reduce went through the host
                  "devices": idents, "distinct_devices": len(set(idents)) if not str(idents[0]).startswith("unavailable") else None,
                  "note": "step_ms = each rank's own mean over the timed steps, median_step_ms = its median by HIP events; compute_ms (HIP events) and "
                          "allreduce_wait_ms (host clock from this rank's compute done to its all-reduce done: "

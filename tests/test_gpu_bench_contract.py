@@ -115,6 +115,25 @@ def test_bench_adopts_the_launchers_world_size_without_gpus_flag():
     assert pr["allreduce_wait_ms_min_over_predicted_allreduce"] is not None
 
 
+def test_bench_falls_back_to_a_host_staged_group_when_rccl_cannot_start():
+    """First contact, last resort: when RCCL cannot be initialised (emulated: LITHO_BENCH_FORCE_RCCL_FAIL=1) the ranks regroup over
+    gloo on the next port and the line says so (`ranks.backend_fallback`) -- a labelled record instead of none."""
+    env = dict(os.environ, LITHO_BENCH_SHARE_GPU="1", LITHO_BENCH_FORCE_RCCL_FAIL="1")
+    for k in ("WORLD_SIZE", "RANK", "LITHO_BENCH_BACKEND"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cfg1", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 2 and r["ranks"]["backend"] == "gloo" and "FORCE_RCCL_FAIL" in r["ranks"]["backend_fallback"]
+    assert r["ranks"]["source_points"] == [1617, 1616] and r["value"] > 1e9
+    # and with the fallback switched off the same failure ends the run with the rank named
+    env["LITHO_BENCH_NO_FALLBACK"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cfg1", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode != 0 and "bench.py: rank" in out.stderr
+
+
 def test_bench_missing_peer_ends_in_seconds_with_the_rank_named():
     """First-contact insurance: WORLD_SIZE = 2 but only rank 0 is ever started (a peer that died before the rendezvous).  The
     rendezvous timeout (LITHO_BENCH_TIMEOUT_S) ends rank 0 with a non-zero code and its name on stderr instead of the lease."""

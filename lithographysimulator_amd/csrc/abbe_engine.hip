@@ -482,6 +482,7 @@ const SizeOps* size_ops(int log2n)
 struct PinnedWords {
     int* p = nullptr;          // host address
     int* dp = nullptr;         // the same buffer as kernels see it (device-mapped, coherent), nullptr if unavailable
+    int dev = -1;              // the device dp was obtained on: calls on another device of the same thread take the copy route
     int seq = 0;               // sequence number of the last k_plan_finish that was asked to publish here
     bool tried = false;
     ~PinnedWords() { if (p) (void)hipHostFree(p); }          // thread exit: a host application's short-lived worker threads do not leak
@@ -505,6 +506,7 @@ static PinnedWords& pinned_state()
             if (off && off[0] == '1') d = nullptr;
             else if (hipHostGetDevicePointer(&d, q, 0) != hipSuccess) { d = nullptr; (void)hipGetLastError(); }
             pw.dp = (int*)d;
+            if (hipGetDevice(&pw.dev) != hipSuccess) { pw.dev = -1; pw.dp = nullptr; (void)hipGetLastError(); }
         } else {
             (void)hipGetLastError();
         }
@@ -538,13 +540,15 @@ static int gather_plan(const Workspace& w, const float2* P, int planes, int pn, 
     if ((size_t)(nb_box + nb_ext) * PLAN_PART * sizeof(int) > w.t_bytes) return LITHO_E_WORKSPACE;
     int* part = (int*)w.T;
     PinnedWords& pw = pinned_state();
-    const int seq = pw.dp ? (pw.seq = pw.seq == INT_MAX ? 1 : pw.seq + 1) : 0;
+    int cur = -2;
+    int* const dp = (pw.dp && hipGetDevice(&cur) == hipSuccess && cur == pw.dev) ? pw.dp : nullptr;
+    const int seq = dp ? (pw.seq = pw.seq == INT_MAX ? 1 : pw.seq + 1) : 0;
     hipLaunchKernelGGL(k_plan_gather, dim3(nb_box + nb_ext), dim3(256), 0, st, P, pn, pn / 2 - pe / 4, pn / 2 + pe / 4, nb_box_x, nb_box,
                        shifts, (long long)S, count_dev, nb_ext, part);
     hipLaunchKernelGGL(k_plan_finish, dim3(1), dim3(256), 0, st, part, nb_box, nb_ext, (long long)S, count_dev, w.plan,
-                       (volatile int*)pw.dp, seq);
+                       (volatile int*)dp, seq);
     HIP_TRY(hipGetLastError());
-    if (pw.dp) {
+    if (dp) {
         // Poll the flag for a while (the wait is a few microseconds when the stream is otherwise idle -- an image sequence --
         // and an interrupt-driven wake-up costs more than that); with a long queue in front, sleep in the runtime instead.
         volatile int* hw = pw.p;

@@ -24,7 +24,7 @@ def test_bench_json_contract():
     assert r["n_gpus"] == 1 and r["steps"] == 2 and r["warmup"] == 1 and r["higher_is_better"] is True
     # per-step HIP-event times and their median beside the contract's mean over the fenced region
     assert len(r["step_ms"]) == 2 and min(r["step_ms"]) > 0 and min(r["step_ms"]) <= r["median_ms_per_step"] <= max(r["step_ms"])
-    assert r["median_ms_per_step"] <= r["ms_per_step"] * 1.5 and abs(r["value_at_median"] - 3233 * 256 * 256 / (r["median_ms_per_step"] * 1e-3)) < 1e-3 * r["value"]
+    assert r["median_ms_per_step"] <= r["ms_per_step"] * 4 and abs(r["value_at_median"] - 3233 * 256 * 256 / (r["median_ms_per_step"] * 1e-3)) < 1e-3 * r["value"]
     assert r["vs_baseline"] is None and r["data"] == "synthetic" and r["value"] > 1e9
     assert "workload" in r["config"] and r["config"]["source_points"] == 3233
     rl = r["roofline"]

@@ -127,31 +127,36 @@ def ptr(t):
 
 
 _workspaces = {}
+_workspaces_lock = threading.Lock()
 WORKSPACE_CACHE_BYTES = 8 << 30      # the cache keeps at most this much per device (one entry always stays)
 
 
 def workspace(device, pn, N):
-    """Scratch buffer for the Abbe / field / mask-spectrum calls, cached per (device, pn, N): 0.3 GiB at 256^2 ..
-    1.3 GiB at 2048^2, 4.6 GiB from 4096^2 up (litho_abbe_workspace_bytes).
+    """Scratch buffer for the Abbe / field / mask-spectrum calls, cached per (device, pn, N, calling thread, stream): 0.3 GiB at
+    256^2 .. 1.3 GiB at 2048^2, 4.6 GiB from 4096^2 up (litho_abbe_workspace_bytes).
 
     Lifetime: the cache only DROPS ITS OWN REFERENCE when it evicts an entry (least recently used first, once a device's
     entries exceed WORKSPACE_CACHE_BYTES) -- a workspace that a PlanCache holds (and therefore every HIP graph captured
     through that PlanCache, whose kernels carry the raw pointer) stays allocated for as long as the PlanCache lives.
     Entries of other devices are never touched."""
     dev_index = device.index if device.index is not None else torch.cuda.current_device()
-    key = (dev_index, pn, N)
-    ws = _workspaces.pop(key, None)
-    if ws is None:
-        nbytes = c_size_t(0)
-        check(lib().litho_abbe_workspace_bytes(pn, N, ctypes.byref(nbytes)), "litho_abbe_workspace_bytes")
-        mine = [k for k in _workspaces if k[0] == dev_index]                   # insertion order = least recently used first
-        held = sum(_workspaces[k].numel() for k in mine)
-        for k in mine:
-            if held + nbytes.value <= WORKSPACE_CACHE_BYTES:
-                break
-            held -= _workspaces.pop(k).numel()
-        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
-    _workspaces[key] = ws                                                      # (re)insert as most recently used
+    # One workspace per (device, size) AND per calling thread and stream: a workspace is scratch of the call that runs in it, so
+    # two Python threads (ctypes releases the GIL inside the library) or two streams must never share one.  The single-threaded,
+    # single-stream caller -- the reference's usage -- sees exactly one entry per size, as before.
+    key = (dev_index, pn, N, threading.get_ident(), int(torch.cuda.current_stream(device).cuda_stream))
+    with _workspaces_lock:
+        ws = _workspaces.pop(key, None)
+        if ws is None:
+            nbytes = c_size_t(0)
+            check(lib().litho_abbe_workspace_bytes(pn, N, ctypes.byref(nbytes)), "litho_abbe_workspace_bytes")
+            mine = [k for k in _workspaces if k[0] == dev_index]               # insertion order = least recently used first
+            held = sum(_workspaces[k].numel() for k in mine)
+            for k in mine:
+                if held + nbytes.value <= WORKSPACE_CACHE_BYTES:
+                    break
+                held -= _workspaces.pop(k).numel()
+            ws = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws                                                  # (re)insert as most recently used
     # The engine launches on torch's CURRENT stream, which need not be the stream the block was allocated on; the caching
     # allocator orders reuse only against the allocation stream.  Recording the use keeps an evicted (or cleared) workspace
     # from being handed out again while Abbe kernels queued on this stream still read or write it (round-4 advice).

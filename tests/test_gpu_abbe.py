@@ -1506,3 +1506,54 @@ def test_largest_size_8192_self_consistent(L, dev, monkeypatch):
     e = float((got - want).abs().max() / scale)
     print(f"8192^2, one source point, 24 rows against the float64 closed form: rel-to-max {e:.2e} (row maxima up to {float(want.max()) / scale:.2f} of the image maximum)")
     assert e < TOL_IMAGE_MAX and float(want.max()) > 0.2 * scale
+
+
+def test_concurrent_threads_and_streams_get_their_own_workspaces(L, dev):
+    """The C ABI may be driven from several host threads, one stream each (ctypes releases the GIL inside the library): every
+    thread x stream gets its OWN workspace from the Python cache (round 6: the cache used to be keyed on the size alone, and two
+    threads at one size would have shared scratch).  Four threads, same size, different masks and source lists, 12 images each
+    on their own streams, against the same images computed one after the other: bit-identical; and the thread-local
+    introspection (last_plan) of one thread is not disturbed by the others."""
+    import threading
+    from lithographysimulator_amd import _native as nat
+    from lithographysimulator_amd.synthetic import bernoulli_mask
+    pn = 256
+    bm = L.LightSource(0.0, 0.5, pn, NA, device=dev).generateAnnular()
+    sh_all = L.sourceShifts(bm, pn)
+    pf = L.Pupil(pn, WL, NA, f16(DEMO_AB), dev).generatePupilFunction()
+    jobs = []
+    for t in range(4):
+        geo = bernoulli_mask(pn).roll(7 * t, 0)
+        mask = L.Mask(geo, PS, dev)
+        mft = mask.fraunhofer(WL, True)
+        sel = sh_all[t::4][: 600 + 50 * t].contiguous()
+        jobs.append((mft, sel))
+    N = 2 * pn
+    serial = [L.abbeIntensity(mft, pf, sel, N).clone() for mft, sel in jobs]
+    torch.cuda.synchronize()
+    results, plans, errors = [None] * 4, [None] * 4, []
+
+    def work(t):
+        try:
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream):
+                out = None
+                for _ in range(12):
+                    out = L.abbeIntensity(jobs[t][0], pf, jobs[t][1], N)
+                plans[t] = nat.last_plan()
+                stream.synchronize()
+                results[t] = out
+        except Exception as exc:                                  # surfaces in the main thread below
+            errors.append(repr(exc))
+
+    before = len(nat._workspaces)
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t in range(4):
+        assert torch.equal(results[t], serial[t]), t
+        assert plans[t]["batch"] > 0 and plans[t]["box_rows"] == 129
+    assert len(nat._workspaces) >= before + 4                     # one workspace per thread x stream

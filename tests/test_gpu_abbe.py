@@ -1541,12 +1541,13 @@ def test_concurrent_threads_and_streams_get_their_own_workspaces(L, dev):
                 for _ in range(12):
                     out = L.abbeIntensity(jobs[t][0], pf, jobs[t][1], N)
                 plans[t] = nat.last_plan()
+                spaces[t] = nat.workspace(dev, pn, N)             # this thread x stream's entry of the cache (kept alive below)
                 stream.synchronize()
                 results[t] = out
         except Exception as exc:                                  # surfaces in the main thread below
             errors.append(repr(exc))
 
-    before = len(nat._workspaces)
+    spaces = [None] * 4
     threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
     for th in threads:
         th.start()
@@ -1556,4 +1557,4 @@ def test_concurrent_threads_and_streams_get_their_own_workspaces(L, dev):
     for t in range(4):
         assert torch.equal(results[t], serial[t]), t
         assert plans[t]["batch"] > 0 and plans[t]["box_rows"] == 129
-    assert len(nat._workspaces) >= before + 4                     # one workspace per thread x stream
+    assert len({ws.data_ptr() for ws in spaces}) == 4             # one workspace per thread x stream
